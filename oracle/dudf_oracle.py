@@ -1,0 +1,322 @@
+# coding: utf-8
+"""ORACLE — test infrastructure only.  Never imported by the product path.
+
+CPU restatement of DiffUDF's training hot path (reference = LIA-DiTella/DiffUDF):
+SIREN forward, the input derivatives the reference obtains by repeated
+`torch.autograd.grad`, the hyperbolic-scaled UDF losses, and `loss.backward()`
+to the parameters — written out as explicit per-layer recurrences (SURVEY.md
+Appendix A) instead of an autograd tape, so that every intermediate the HIP
+kernels produce can be checked one by one.
+
+Parity pin: this file is checked against golden vectors produced by importing
+the reference itself (`tests/golden/make_golden.py`, fixtures `tests/golden/*.npz`)
+in `tests/test_oracle_golden.py`.  The reference has no tests / golden vectors of
+its own, so those generated fixtures are the pin.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module.
+
+Array backend: every function takes `xp` = `numpy` (default, any float dtype) or
+`torch` (CPU tensors; used for the multi-threaded cpu_baseline timing).  Only
+operators and functions that exist under the same name in both are used.
+
+Conventions: params = [(W_1,b_1), ..., (W_L,b_L), (W_out,b_out)], W (out,in)
+row-major as `nn.Linear` stores it; x (N,3); everything is per point, no leading
+batch-of-1 dimension (the reference carries one: (1,N,3)).
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# forward value  —  reference src/model.py:29-30 (SineLayer), :131-135 (SIREN.forward)
+# --------------------------------------------------------------------------
+def forward(params, x, w0=30.0, xp=np):
+    """y (N,), cache = {'s': [s_1..s_L], 'c': [c_1..c_L]} with s_l = sin(w0 z_l), c_l = cos(w0 z_l)."""
+    h = x
+    S, C = [], []
+    for W, b in params[:-1]:
+        z = xp.matmul(h, W.T) + b            # nn.Linear
+        t = w0 * z                           # SineLayer: torch.sin(self.w0 * x)
+        s = xp.sin(t)
+        S.append(s)
+        C.append(xp.cos(t))
+        h = s
+    Wo, bo = params[-1]
+    y = (xp.matmul(h, Wo.T) + bo)[:, 0]
+    return y, {"s": S, "c": C}
+
+
+# --------------------------------------------------------------------------
+# dy/dx by one reverse sweep  —  reference src/diff_operators.py:208-212 `gradient`
+# --------------------------------------------------------------------------
+def input_gradient(params, cache, w0=30.0, xp=np):
+    """g (N,3) and the per-layer reverse quantities a_l (adjoint of h_l), q_l = w0 c_l a_l."""
+    L = len(params) - 1
+    N = cache["c"][0].shape[0]
+    Wo = params[-1][0]
+    a = Wo[0][None, :] + 0.0 * cache["c"][-1]          # a_L = W_out^T broadcast to (N,H)
+    A, Q = [None] * L, [None] * L
+    for l in range(L - 1, -1, -1):
+        A[l] = a
+        q = w0 * cache["c"][l] * a
+        Q[l] = q
+        a = xp.matmul(q, params[l][0])                  # a_{l-1} = W_l^T q_l
+    return a, {"a": A, "q": Q}
+
+
+# --------------------------------------------------------------------------
+# Hessian  —  reference src/diff_operators.py:187-193 `hessian` (rows h_i = grad(g[:,i], x))
+# forward-over-reverse with three tangents
+# --------------------------------------------------------------------------
+def hessian(params, x, cache, rev, w0=30.0, xp=np):
+    """H (N,3,3) with H[n,i,k] = d(df/dx_i)/dx_k, plus the tangent caches (zd[k][l], ad[k][l])."""
+    L = len(params) - 1
+    cols, zd_all, ad_all = [], [], []
+    for k in range(3):
+        hd = 0.0 * x                                     # forward tangents: hdot_0 = e_k
+        hd[:, k] = 1.0
+        zd = []
+        for l in range(L):
+            zk = xp.matmul(hd, params[l][0].T)          # zdot_l = W_l hdot_{l-1}
+            zd.append(zk)
+            hd = w0 * cache["c"][l] * zk               # hdot_l = w0 c_l zdot_l
+        ad = 0.0 * cache["c"][-1]                        # reverse tangents: adot_L = 0
+        adk = [None] * L
+        for l in range(L - 1, -1, -1):
+            adk[l] = ad
+            cd = -w0 * cache["s"][l] * zd[l]           # d c_l / d x_k
+            qd = w0 * (cd * rev["a"][l] + cache["c"][l] * ad)
+            ad = xp.matmul(qd, params[l][0])            # adot_{l-1} = W_l^T qdot_l
+        cols.append(ad)                                 # (N,3) indexed by i: column k of H
+        zd_all.append(zd)
+        ad_all.append(adk)
+    H = xp.stack(cols, -1)
+    return H, {"zd": zd_all, "ad": ad_all}
+
+
+# --------------------------------------------------------------------------
+# small helpers shared by the losses
+# --------------------------------------------------------------------------
+def _norm(v, xp):
+    return xp.sqrt((v * v).sum(-1))
+
+
+def _cos_sim(a, b, xp, eps=1e-8):
+    """F.cosine_similarity(a, b, dim=-1): each norm clamped to eps (SURVEY.md §8(a) A7 [probe])."""
+    na = xp.clip(_norm(a, xp), eps, None)
+    nb = xp.clip(_norm(b, xp), eps, None)
+    return (a * b).sum(-1) / (na * nb)
+
+
+def top_eigvec(H, xp=np):
+    """Eigenvector of the largest eigenvalue, lower triangle only, ascending order —
+    reference src/loss_functions.py:141-143 (`torch.linalg.eigh`, `eigenvectors[..., 2]`)."""
+    if xp is np:
+        lam, V = np.linalg.eigh(H)          # UPLO='L'
+    else:
+        lam, V = xp.linalg.eigh(H)
+    return lam, V
+
+
+# --------------------------------------------------------------------------
+# loss_s1  —  reference src/loss_functions.py:123-155 (+ :9-22, :45-53)
+# --------------------------------------------------------------------------
+def loss_s1_terms(y, g, H, normals, sdf, weights, alpha, xp=np):
+    """Dict of the four weighted scalars + the per-point cotangents (ybar, gbar[, nbar]) of their SUM.
+
+    `H` may be None when weights[2] == 0 (the reference then skips the Hessian entirely).
+    """
+    N = y.shape[0]
+    u = sdf[:, 0]
+    on = (u == 0)
+    tan = xp.tanh(alpha * u)
+    tdf = u * tan
+    zero = 0.0 * y
+    t_on = xp.where(on, xp.abs(y), zero)                              # sdf_constraint_on_surf  :9-14
+    t_off = xp.where(on, zero, xp.abs(tdf - y))                       # sdf_constraint_off_surf :17-22
+    out = {
+        "sdf_on_surf": t_on.mean() * weights[0],
+        "sdf_off_surf": t_off.mean() * weights[1],
+    }
+    ybar = (weights[0] / N) * xp.where(on, xp.sign(y), zero) - (weights[1] / N) * xp.where(on, zero, xp.sign(tdf - y))
+    cot = {"ybar": ybar}
+    if weights[2] != 0:
+        lam, V = top_eigvec(H, xp)
+        n = V[..., 2]
+        cs = _cos_sim(normals, n, xp)
+        t_h = xp.where(on, 1.0 - xp.abs(cs), zero)                    # principal_curvature_alignment :45-53
+        out["hessian_constraint"] = t_h.mean() * weights[2]
+        cot["lam"], cot["V"], cot["cos"] = lam, V, cs
+    else:
+        out["hessian_constraint"] = 0.0 * out["sdf_on_surf"]          # torch.Tensor([0])  :147
+    if weights[3] != 0:
+        gn = _norm(g, xp)
+        target = xp.abs(tan + u * alpha * (1.0 - tan * tan))         # :136
+        d = gn - target
+        out["grad_constraint"] = xp.abs(d).mean() * weights[3]
+        safe = xp.where(gn > 0, gn, 1.0 + zero)
+        cot["gbar"] = ((weights[3] / N) * xp.sign(d) * xp.where(gn > 0, 1.0 / safe, zero))[:, None] * g
+    else:
+        out["grad_constraint"] = 0.0 * out["sdf_on_surf"]
+        cot["gbar"] = None
+    # keep reference key order (losses.csv column order): on, off, hessian, grad
+    out = {k: out[k] for k in ("sdf_on_surf", "sdf_off_surf", "hessian_constraint", "grad_constraint")}
+    return out, cot
+
+
+# --------------------------------------------------------------------------
+# loss_siren  —  reference src/loss_functions.py:82-104 (+ :24-32)
+# --------------------------------------------------------------------------
+def loss_siren_terms(y, g, normals, sdf, weights, xp=np):
+    N = y.shape[0]
+    s = sdf[:, 0]
+    on = (s == 0)
+    zero = 0.0 * y
+    ay = xp.abs(y)
+    ex = xp.exp(-1e2 * ay)
+    gn = _norm(g, xp)
+    mn = _norm(normals, xp)
+    cs = _cos_sim(g, normals, xp)
+    out = {
+        "sdf_on_surf": xp.where(on, ay, zero).mean() * weights[0],
+        "sdf_off_surf": xp.where(on, zero, ex).mean() * weights[1],
+        "normal_constraint": xp.where(on, 1.0 - cs, zero).mean() * weights[2],
+        "grad_constraint": ((gn - 1.0) ** 2).mean() * weights[3],
+    }
+    ybar = (weights[0] / N) * xp.where(on, xp.sign(y), zero) - (weights[1] / N) * xp.where(on, zero, 1e2 * xp.sign(y) * ex)
+    gnc = xp.clip(gn, 1e-8, None)
+    mnc = xp.clip(mn, 1e-8, None)
+    # d cos / d g with the clamped-norm form; inside the clamp (|g| < eps) the norm factor is constant
+    dcos = normals / (gnc * mnc)[:, None] - xp.where(gn > 1e-8, cs / (gnc * gnc), zero)[:, None] * g
+    safe = xp.where(gn > 0, gn, 1.0 + zero)
+    gbar = -(weights[2] / N) * xp.where(on, 1.0 + zero, zero)[:, None] * dcos \
+        + ((weights[3] / N) * 2.0 * (gn - 1.0) * xp.where(gn > 0, 1.0 / safe, zero))[:, None] * g
+    return out, {"ybar": ybar, "gbar": gbar}
+
+
+# --------------------------------------------------------------------------
+# loss_s2  —  reference src/loss_functions.py:106-121
+# --------------------------------------------------------------------------
+def loss_s2_terms(y, sdf, weights, xp=np, stats=None):
+    """`stats` = (n, sum, sumsq) of the on-surface predictions over the GLOBAL batch; when None it
+    is formed from this batch (single-rank case)."""
+    u = sdf[:, 0]
+    on = (u == 0)
+    zero = 0.0 * y
+    p = xp.where(on, y, zero)
+    if stats is None:
+        n = on.sum() * 1.0
+        sm = p.sum()
+        sq = (p * p).sum()
+    else:
+        n, sm, sq = stats
+    mu = sm / n
+    var = (sq - n * mu * mu) / (n - 1.0)                  # torch.std: unbiased
+    if stats is None:                                      # two-pass form when the data is local (better conditioned)
+        var = (xp.where(on, (y - mu) ** 2, zero)).sum() / (n - 1.0)
+    sd = xp.sqrt(var)
+    out = {"sdf_on_surf": xp.abs(mu) * weights[0], "std_on_surf": sd * weights[1]}
+    ybar = xp.where(on, weights[0] * xp.sign(mu) / n + weights[1] * (y - mu) / ((n - 1.0) * sd), zero)
+    return out, {"ybar": ybar, "gbar": None}
+
+
+# --------------------------------------------------------------------------
+# loss.backward() to the parameters  —  reference train.py:221 through
+# src/loss_functions.py / src/diff_operators.py graphs; SURVEY.md Appendix A.5, Eikonal subset
+# --------------------------------------------------------------------------
+def param_grad(params, x, cache, rev, ybar, gbar, w0=30.0, xp=np):
+    """d(sum of loss terms)/d(params) for cotangents ybar (N,) on y and gbar (N,3) on df/dx (or None).
+
+    Returns (grads, trace): grads = [(dW_l, db_l)...] in `params` order; trace holds the per-layer
+    intermediates (A_l, e_l, zbar_l) the HIP sweeps 3 and 4 stash, for stage-by-stage checks.
+    """
+    L = len(params) - 1
+    dW = [0.0 * W for W, _ in params]
+    db = [0.0 * b for _, b in params]
+    s, c = cache["s"], cache["c"]
+    cbar = [None] * L
+    trace = {"A": [None] * L, "e": [None] * L, "zbar": [None] * L}
+    if gbar is not None:
+        # (i) adjoint of the reverse sweep, runs forward in l
+        Aprev = gbar
+        for l in range(L):
+            Ql = xp.matmul(Aprev, params[l][0].T)               # Q_l = W_l A_{l-1}
+            dW[l] = dW[l] + xp.matmul(rev["q"][l].T, Aprev)      # q_l A_{l-1}^T summed over points
+            cbar[l] = w0 * rev["a"][l] * Ql
+            trace["e"][l] = w0 * s[l] * cbar[l]                  # = w0^2 s_l a_l Q_l
+            Aprev = w0 * c[l] * Ql
+            trace["A"][l] = Aprev
+        dW[L] = dW[L] + Aprev.sum(0)[None, :]
+    # (ii) adjoint of the forward sweep, runs backward in l
+    Wo = params[-1][0]
+    hbar = ybar[:, None] * Wo[0][None, :]
+    dW[L] = dW[L] + xp.matmul(ybar[None, :], s[L - 1])
+    db[L] = db[L] + ybar.sum()[None]
+    for l in range(L - 1, -1, -1):
+        zbar = w0 * c[l] * hbar
+        if cbar[l] is not None:
+            zbar = zbar - w0 * s[l] * cbar[l]
+        trace["zbar"][l] = zbar
+        hprev = x if l == 0 else s[l - 1]
+        dW[l] = dW[l] + xp.matmul(zbar.T, hprev)
+        db[l] = db[l] + zbar.sum(0)
+        if l > 0:
+            hbar = xp.matmul(zbar, params[l][0])
+    return list(zip(dW, db)), trace
+
+
+# --------------------------------------------------------------------------
+# one-call conveniences used by the tests / cpu_baseline
+# --------------------------------------------------------------------------
+def query(params, x, w0=30.0, want_grad=True, want_hess=False, xp=np):
+    y, cache = forward(params, x, w0, xp)
+    g = H = None
+    if want_grad or want_hess:
+        g, rev = input_gradient(params, cache, w0, xp)
+    if want_hess:
+        H, _ = hessian(params, x, cache, rev, w0, xp)
+    return y, g, H
+
+
+def loss_and_grad(mode, params, x, normals, sdf, weights, alpha=100.0, w0=30.0, xp=np, s2_stats=None):
+    """mode in {'s1','s2','siren'}.  Returns (terms dict, grads list, debug dict).
+    For mode 's1' with weights[2] != 0 only the TERMS include the Hessian constraint; its
+    parameter gradient needs `param_grad_hessian` (not part of this first slice)."""
+    y, cache = forward(params, x, w0, xp)
+    g, rev = (None, None)
+    if mode in ("s1", "siren"):
+        g, rev = input_gradient(params, cache, w0, xp)
+    H = None
+    if mode == "s1":
+        if weights[2] != 0:
+            H, _ = hessian(params, x, cache, rev, w0, xp)
+        terms, cot = loss_s1_terms(y, g, H, normals, sdf, weights, alpha, xp)
+    elif mode == "siren":
+        terms, cot = loss_siren_terms(y, g, normals, sdf, weights, xp)
+    elif mode == "s2":
+        terms, cot = loss_s2_terms(y, sdf, weights, xp, s2_stats)
+    else:
+        raise ValueError(mode)
+    grads, trace = param_grad(params, x, cache, rev, cot["ybar"], cot.get("gbar"), w0, xp)
+    dbg = {"y": y, "g": g, "H": H, "cache": cache, "rev": rev, "cot": cot, "trace": trace}
+    return terms, grads, dbg
+
+
+def adam_step(theta, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (reference train.py:334-337), one step, in place on numpy arrays.
+    `step` is the 1-based step count AFTER this update."""
+    m *= beta1; m += (1.0 - beta1) * grad
+    v *= beta2; v += (1.0 - beta2) * grad * grad
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = np.sqrt(v) / np.sqrt(bc2) + eps
+    theta -= (lr / bc1) * (m / denom)
+    return theta
+
+
+# --------------------------------------------------------------------------
+# inverse hyperbolic map + MC field extraction pieces — reference src/inverses.py:18-19,
+# src/render_mc.py:72-93
+# --------------------------------------------------------------------------
+def inv_tanh(pred_df, alpha):
+    return np.where(pred_df < 1.0 / alpha, np.sqrt(pred_df / alpha), pred_df)

@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE ITSELF.
+
+Run once, in the build container only (the reference is mounted read-only at
+/root/reference and never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+Inputs (weights, batches) come from `diffudf_amd.synth` (pure functions of a seed), so
+the fixtures only have to carry seeds + the reference's OUTPUTS.  The reference modules
+imported are exactly the hot path: src.model.SIREN, src.diff_operators.{gradient,hessian},
+src.loss_functions.{loss_s1,loss_s2,loss_siren}, src.evaluate.evaluate, src.inverses.inverse,
+plus torch.optim.Adam as the reference's train loop uses it (train.py:334-337, :195-222).
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+from src.model import SIREN                                     # noqa: E402  (reference)
+from src.diff_operators import gradient, hessian                # noqa: E402  (reference)
+from src.loss_functions import loss_s1, loss_s2, loss_siren     # noqa: E402  (reference)
+from src.evaluate import evaluate                               # noqa: E402  (reference)
+from src.inverses import inverse                                # noqa: E402  (reference)
+from diffudf_amd import synth                                   # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def ref_model(hidden, params, dtype):
+    m = SIREN(3, 1, hidden, w0=30)
+    sd = {}
+    for i, (w, b) in enumerate(params):
+        sd[f"net.{i}.0.weight"] = torch.from_numpy(np.asarray(w, dtype=np.float64))
+        sd[f"net.{i}.0.bias"] = torch.from_numpy(np.asarray(b, dtype=np.float64))
+    m = m.double()
+    m.load_state_dict(sd)
+    return m.to(dtype)
+
+
+def flat_grads(model):
+    return np.concatenate([p.grad.detach().reshape(-1).double().numpy() for p in model.parameters()])
+
+
+def run_losses(hidden, params, batch, dtype, tag, out, sample=None):
+    x, nrm, sdf = [torch.from_numpy(a.astype(np.float64)).to(dtype)[None] for a in batch]
+    model = ref_model(hidden, params, dtype)
+    # value / gradient / hessian exactly as src/evaluate.py:26-32 obtains them
+    mo = model(x)
+    xin, y = mo["model_in"], mo["model_out"]
+    g = gradient(y, xin)
+    H = hessian(y, xin)
+    out[f"{tag}_y"] = y.detach().double().numpy()[0, :, 0]
+    out[f"{tag}_g"] = g.detach().double().numpy()[0]
+    out[f"{tag}_H"] = H.detach().double().numpy()[0]
+    gt = {"normals": nrm, "sdf": sdf}
+    cases = {
+        "s1eik": (loss_s1, [1e4, 1e4, 0.0, 1e3], True),
+        "s1full": (loss_s1, [1e4, 1e4, 1e4, 1e3], True),
+        "s2": (loss_s2, [1e5, 1e5], True),
+        "siren": (loss_siren, [3e3, 1e2, 1e2, 5e1], False),
+    }
+    for name, (fn, w, has_alpha) in cases.items():
+        model.zero_grad()
+        terms = fn(model, x, gt, w, 100) if has_alpha else fn(model, x, gt, w)
+        total = torch.zeros((1, 1), dtype=dtype)
+        for v in terms.values():
+            total = total + v
+        total.backward()
+        out[f"{tag}_{name}_terms"] = np.array([float(v) for v in terms.values()])
+        gr = flat_grads(model)
+        if sample is None:
+            out[f"{tag}_{name}_dtheta"] = gr
+        else:
+            out[f"{tag}_{name}_dtheta_sample"] = gr[sample]
+            out[f"{tag}_{name}_dtheta_norm"] = np.array([np.linalg.norm(gr), np.abs(gr).max()])
+
+
+def trajectory(hidden, params, n_pts, steps, lr, mode, weights, dtype, seed):
+    """N Adam steps the way train.py:195-222 runs them (zero_grad, loss dict, sum, backward, step)."""
+    model = ref_model(hidden, params, dtype)
+    opt = torch.optim.Adam(lr=lr, params=model.parameters())
+    fn = {"s1": loss_s1, "s2": loss_s2}[mode]
+    hist = []
+    for t in range(steps):
+        x, nrm, sdf = [torch.from_numpy(a.astype(np.float64)).to(dtype)[None]
+                       for a in synth.training_batch(n_pts, seed=seed, step=t, dtype=np.float64)]
+        opt.zero_grad()
+        terms = fn(model, x, {"normals": nrm, "sdf": sdf}, weights, 100)
+        total = torch.zeros((1, 1), dtype=dtype)
+        for v in terms.values():
+            total = total + v
+        total.backward()
+        opt.step()
+        hist.append([float(v) for v in terms.values()])
+    theta = np.concatenate([p.detach().reshape(-1).double().numpy() for p in model.parameters()])
+    return np.array(hist), theta
+
+
+def main():
+    # ---- G1: tiny net, everything stored --------------------------------------------------
+    out = {}
+    hid = [32, 32, 32]
+    p64 = synth.siren_params(hid, seed=7, dtype=np.float64)
+    batch = synth.training_batch(63, seed=7, dtype=np.float64)
+    out["hidden"] = np.array(hid)
+    out["param_seed"] = np.array(7); out["batch_seed"] = np.array(7); out["n_points"] = np.array(63)
+    run_losses(hid, p64, batch, torch.float64, "f64", out)
+    # the fp32 run uses fp32-rounded weights and inputs (what a user of the reference has)
+    p32 = [(w.astype(np.float32), b.astype(np.float32)) for w, b in p64]
+    b32 = [a.astype(np.float32) for a in batch]
+    run_losses(hid, p32, b32, torch.float32, "f32", out)
+    np.savez_compressed(os.path.join(HERE, "g1_tiny.npz"), **out)
+
+    # ---- G2: full 8x256, sampled parameter gradients ---------------------------------------
+    out = {}
+    hid = [256] * 8
+    p32 = synth.siren_params(hid, seed=123, dtype=np.float32)
+    b32 = synth.training_batch(192, seed=123, dtype=np.float32)
+    n_theta = synth.flatten_params(p32).size
+    sample = np.arange(0, n_theta, 61)
+    out["hidden"] = np.array(hid); out["sample"] = sample
+    out["param_seed"] = np.array(123); out["batch_seed"] = np.array(123); out["n_points"] = np.array(192)
+    # fp64 arithmetic on the fp32-representable weights/inputs = the "exact" answer for those inputs
+    run_losses(hid, p32, b32, torch.float64, "f64", out, sample)
+    run_losses(hid, p32, b32, torch.float32, "f32", out, sample)
+    np.savez_compressed(os.path.join(HERE, "g2_8x256.npz"), **out)
+
+    # ---- G3: N-step Adam trajectories --------------------------------------------------------
+    out = {}
+    hid = [64] * 4
+    p32 = synth.siren_params(hid, seed=11, dtype=np.float32)
+    for name, mode, w, lr in (("s1eik", "s1", [1e4, 1e4, 0.0, 1e3], 1e-4), ("s2", "s2", [1e5, 1e5], 1e-6)):
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            hist, theta = trajectory(hid, p32, 384, 20, lr, mode, w, dt, seed=11)
+            out[f"{name}_{tag}_hist"] = hist
+            out[f"{name}_{tag}_theta"] = theta
+    out["hidden"] = np.array(hid); out["param_seed"] = np.array(11); out["batch_seed"] = np.array(11)
+    out["n_points"] = np.array(384); out["steps"] = np.array(20)
+    np.savez_compressed(os.path.join(HERE, "g3_traj.npz"), **out)
+
+    out = {}
+    hid = [256] * 8
+    p32 = synth.siren_params(hid, seed=123, dtype=np.float32)
+    n_theta = synth.flatten_params(p32).size
+    sample = np.arange(0, n_theta, 61)
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        hist, theta = trajectory(hid, p32, 1024, 10, 1e-4, "s1", [1e4, 1e4, 0.0, 1e3], dt, seed=123)
+        out[f"s1eik_{tag}_hist"] = hist
+        out[f"s1eik_{tag}_theta_sample"] = theta[sample]
+    out["hidden"] = np.array(hid); out["sample"] = sample; out["param_seed"] = np.array(123)
+    out["batch_seed"] = np.array(123); out["n_points"] = np.array(1024); out["steps"] = np.array(10)
+    np.savez_compressed(os.path.join(HERE, "g3_traj_8x256.npz"), **out)
+
+    # ---- G4: chunked query through src.evaluate.evaluate on a small grid ----------------------
+    out = {}
+    hid = [256] * 8
+    p32 = synth.siren_params(hid, seed=123, dtype=np.float32)
+    model = ref_model(hid, p32, torch.float32)
+    n = 12
+    ax = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    grads = np.zeros((n ** 3, 3)); hess = np.zeros((n ** 3, 3, 3))
+    vals = evaluate(model, grid, max_batch=500, device=torch.device("cpu"), gradients=grads, hessians=hess)
+    out["grid_n"] = np.array(n); out["values"] = vals; out["gradients"] = grads; out["hessians"] = hess
+    out["inv_tanh"] = inverse("tanh", np.abs(vals), 100)
+    np.savez_compressed(os.path.join(HERE, "g4_query.npz"), **out)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

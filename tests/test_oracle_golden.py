@@ -1,0 +1,139 @@
+# coding: utf-8
+"""Pin the oracle (oracle/dudf_oracle.py) against vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import os
+import numpy as np
+import pytest
+
+from diffudf_amd import synth
+from oracle import dudf_oracle as O
+
+W_S1EIK = [1e4, 1e4, 0.0, 1e3]
+W_S1FULL = [1e4, 1e4, 1e4, 1e3]
+W_S2 = [1e5, 1e5]
+W_SIREN = [3e3, 1e2, 1e2, 5e1]
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def flat(grads):
+    return np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
+
+
+@pytest.fixture(scope="module")
+def g1(golden_dir):
+    return np.load(os.path.join(golden_dir, "g1_tiny.npz"))
+
+
+@pytest.fixture(scope="module")
+def g2(golden_dir):
+    return np.load(os.path.join(golden_dir, "g2_8x256.npz"))
+
+
+def test_g1_fields_fp64(g1):
+    hid = list(g1["hidden"])
+    P = synth.siren_params(hid, seed=int(g1["param_seed"]), dtype=np.float64)
+    x, nrm, sdf = synth.training_batch(int(g1["n_points"]), seed=int(g1["batch_seed"]), dtype=np.float64)
+    y, g, H = O.query(P, x, want_grad=True, want_hess=True)
+    assert rel(y, g1["f64_y"]) < 1e-13
+    assert rel(g, g1["f64_g"]) < 1e-13
+    assert rel(H, g1["f64_H"]) < 1e-12
+
+
+@pytest.mark.parametrize("case,mode,w", [("s1eik", "s1", W_S1EIK), ("s2", "s2", W_S2), ("siren", "siren", W_SIREN)])
+def test_g1_loss_and_param_grads_fp64(g1, case, mode, w):
+    hid = list(g1["hidden"])
+    P = synth.siren_params(hid, seed=int(g1["param_seed"]), dtype=np.float64)
+    x, nrm, sdf = synth.training_batch(int(g1["n_points"]), seed=int(g1["batch_seed"]), dtype=np.float64)
+    terms, grads, _ = O.loss_and_grad(mode, P, x, nrm, sdf, w, 100.0)
+    got = np.array([float(v) for v in terms.values()])
+    assert rel(got, g1[f"f64_{case}_terms"]) < 1e-12
+    assert rel(flat(grads), g1[f"f64_{case}_dtheta"]) < 1e-11
+
+
+def test_g1_full_s1_terms_fp64(g1):
+    """Hessian-on loss_s1: all four TERMS (the eigh-based one included)."""
+    hid = list(g1["hidden"])
+    P = synth.siren_params(hid, seed=int(g1["param_seed"]), dtype=np.float64)
+    x, nrm, sdf = synth.training_batch(int(g1["n_points"]), seed=int(g1["batch_seed"]), dtype=np.float64)
+    y, g, H = O.query(P, x, want_grad=True, want_hess=True)
+    terms, _ = O.loss_s1_terms(y, g, H, nrm, sdf, W_S1FULL, 100.0)
+    got = np.array([float(v) for v in terms.values()])
+    assert rel(got, g1["f64_s1full_terms"]) < 1e-10
+
+
+def test_g1_fp32_oracle_within_reference_noise(g1):
+    """The oracle run in fp32 must sit inside the reference's own fp32-vs-fp64 noise band."""
+    hid = list(g1["hidden"])
+    P = synth.siren_params(hid, seed=int(g1["param_seed"]), dtype=np.float64)
+    P32 = [(w.astype(np.float32), b.astype(np.float32)) for w, b in P]
+    x, nrm, sdf = [a.astype(np.float32) for a in
+                   synth.training_batch(int(g1["n_points"]), seed=int(g1["batch_seed"]), dtype=np.float64)]
+    y, g, H = O.query(P32, x, want_grad=True, want_hess=True)
+    assert y.dtype == np.float32
+    assert rel(y, g1["f32_y"]) < 2e-5
+    assert rel(g, g1["f32_g"]) < 5e-5
+    assert rel(H, g1["f32_H"]) < 1e-4
+
+
+def test_g2_8x256_fields_and_grads(g2):
+    hid = list(g2["hidden"])
+    P32 = synth.siren_params(hid, seed=int(g2["param_seed"]), dtype=np.float32)
+    P = [(w.astype(np.float64), b.astype(np.float64)) for w, b in P32]
+    x, nrm, sdf = [a.astype(np.float64) for a in
+                   synth.training_batch(int(g2["n_points"]), seed=int(g2["batch_seed"]), dtype=np.float32)]
+    y, g, H = O.query(P, x, want_grad=True, want_hess=True)
+    assert rel(y, g2["f64_y"]) < 1e-12
+    assert rel(g, g2["f64_g"]) < 1e-12
+    assert rel(H, g2["f64_H"]) < 1e-11
+    sample = g2["sample"]
+    for case, mode, w in (("s1eik", "s1", W_S1EIK), ("s2", "s2", W_S2), ("siren", "siren", W_SIREN)):
+        terms, grads, _ = O.loss_and_grad(mode, P, x, nrm, sdf, w, 100.0)
+        got = np.array([float(v) for v in terms.values()])
+        assert rel(got, g2[f"f64_{case}_terms"]) < 1e-11, case
+        fg = flat(grads)
+        assert rel(fg[sample], g2[f"f64_{case}_dtheta_sample"]) < 1e-10, case
+        nrm_ref = g2[f"f64_{case}_dtheta_norm"]
+        assert abs(np.linalg.norm(fg) - nrm_ref[0]) / nrm_ref[0] < 1e-10, case
+    # the reference's own fp32 noise against its fp64 run: documents the tolerance the HIP tests use
+    assert rel(g2["f32_y"], g2["f64_y"]) < 2e-5
+    assert rel(g2["f32_g"], g2["f64_g"]) < 5e-5
+
+
+def test_g3_trajectory_small_net(golden_dir):
+    """20 Adam steps of loss_s1 (Eikonal-only) and loss_s2 on a 4x64 net follow the reference curve."""
+    G = np.load(os.path.join(golden_dir, "g3_traj.npz"))
+    hid = list(G["hidden"])
+    P32 = synth.siren_params(hid, seed=int(G["param_seed"]), dtype=np.float32)
+    for name, mode, w, lr in (("s1eik", "s1", W_S1EIK, 1e-4), ("s2", "s2", W_S2, 1e-6)):
+        theta = synth.flatten_params(P32, dtype=np.float64)
+        m = np.zeros_like(theta); v = np.zeros_like(theta)
+        hist = []
+        for t in range(int(G["steps"])):
+            x, nrm, sdf = [a.astype(np.float64) for a in
+                           synth.training_batch(int(G["n_points"]), seed=int(G["batch_seed"]), step=t, dtype=np.float64)]
+            P = synth.unflatten_params(theta, hid)
+            terms, grads, _ = O.loss_and_grad(mode, P, x, nrm, sdf, w, 100.0)
+            hist.append([float(vv) for vv in terms.values()])
+            O.adam_step(theta, flat(grads), m, v, t + 1, lr)
+        hist = np.array(hist)
+        # kinks (abs / sign) make long trajectories chaotic at the 1e-10 level; 1e-6 relative is ample
+        assert rel(hist, G[f"{name}_f64_hist"]) < 1e-6, name
+        assert rel(theta, G[f"{name}_f64_theta"]) < 1e-6, name
+
+
+def test_g4_query_and_inverse(golden_dir):
+    G = np.load(os.path.join(golden_dir, "g4_query.npz"))
+    n = int(G["grid_n"])
+    P32 = synth.siren_params([256] * 8, seed=123, dtype=np.float32)
+    ax = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    P = [(w.astype(np.float64), b.astype(np.float64)) for w, b in P32]
+    y, g, H = O.query(P, grid.astype(np.float64), want_grad=True, want_hess=True)
+    # fixture is the reference's fp32 evaluate(): compare at the fp32 noise level
+    assert rel(y, G["values"][:, 0]) < 2e-5
+    assert rel(g, G["gradients"]) < 5e-5
+    assert rel(H, G["hessians"]) < 1e-4
+    assert np.allclose(O.inv_tanh(np.abs(G["values"]), 100), G["inv_tanh"], rtol=0, atol=0)
