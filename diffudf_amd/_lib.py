@@ -1,0 +1,78 @@
+# coding: utf-8
+"""ctypes binding of libdudf_hip.so (C ABI declared in include/dudf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdudf_hip.so")
+
+LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
+
+_ERRORS = {
+    -1: "DUDF_E_BADCFG: unsupported network (equal hidden widths in {32,64,128,256}, n_in=3, n_out=1)",
+    -2: "DUDF_E_WORKSPACE: workspace too small or misaligned",
+    -3: "DUDF_E_BADMODE",
+    -4: "DUDF_E_UNSUPPORTED: this loss configuration has no HIP path yet (loss_s1 with a non-zero "
+        "Hessian weight); there is deliberately no CPU fallback",
+}
+
+
+class NetCfg(ctypes.Structure):
+    _fields_ = [("n_in", ctypes.c_int32), ("n_hidden_layers", ctypes.c_int32),
+                ("hidden", ctypes.c_int32), ("w0", ctypes.c_float)]
+
+
+class DudfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/dudf_hip.h declares: (restype, argtypes)
+_P = ctypes.c_void_p
+_CFG = ctypes.POINTER(NetCfg)
+_DBL = ctypes.POINTER(ctypes.c_double)
+SYMBOLS = {
+    "dudf_version": (ctypes.c_char_p, []),
+    "dudf_theta_count": (ctypes.c_int64, [_CFG]),
+    "dudf_workspace_bytes": (ctypes.c_size_t, [_CFG, ctypes.c_int64]),
+    "dudf_query": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_loss_forward": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64,
+                                         _DBL, ctypes.c_double, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_s2_forward_stats": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int64, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_s2_terms": (ctypes.c_int, [_P, _DBL, _P, _P]),
+    "dudf_loss_backward": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64,
+                                          _DBL, ctypes.c_double, _P, _P, _P, ctypes.c_int, _P, ctypes.c_size_t, _P]),
+    "dudf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_double, _P]),
+    "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P,
+                                             ctypes.c_size_t, _P]),
+}
+
+
+def load():
+    """Load libdudf_hip.so (built in-tree by `__graft_entry__.build()` / `make -C diffudf_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DudfError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise DudfError(f"{what}: {_ERRORS.get(rc, rc)}")
+    raise DudfError(f"{what}: HIP error {rc}")

@@ -1,0 +1,314 @@
+// Small kernels around the sweeps: parameter packing, the per-point loss terms and their
+// cotangents, loss_s2 statistics, Adam, and copy-out helpers.  All bandwidth-trivial.
+#include "dudf_internal.h"
+
+namespace {
+
+// ---- pack: A-operand forms of theta --------------------------------------------------------------
+__global__ void pack_kernel(const float* __restrict__ theta, float* __restrict__ w1b, float* __restrict__ w1t16,
+                            float* __restrict__ wt, int H, int L, int64_t off_hid, int64_t hid_stride) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_wt = (int64_t)(L - 1) * H * H;
+    if (gid < n_wt) {                                   // wt[j][i][o] = W_{j+2}[o][i]
+        const int64_t j = gid / ((int64_t)H * H), rem = gid % ((int64_t)H * H);
+        const int i = (int)(rem / H), o = (int)(rem % H);
+        wt[gid] = theta[off_hid + j * hid_stride + (int64_t)o * H + i];
+    }
+    if (gid < 4 * (int64_t)H) {                         // w1b[f][k] = k<3 ? W_1[f][k] : b_1[f]
+        const int f = (int)(gid / 4), k = (int)(gid % 4);
+        w1b[gid] = k < 3 ? theta[f * 3 + k] : theta[3 * H + f];
+    }
+    if (gid < 16 * (int64_t)H) {                        // w1t16[r][f] = r<3 ? W_1[f][r] : 0
+        const int r = (int)(gid / H), f = (int)(gid % H);
+        w1t16[gid] = r < 3 ? theta[f * 3 + r] : 0.f;
+    }
+}
+
+// ---- reductions ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_accumulate(double (&v)[NV], double* __restrict__ acc) {
+    __shared__ double part[NV][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum_d(v[i]);
+        if (lane == 0) part[i][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const double s = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        atomicAdd(acc + threadIdx.x, s);
+    }
+}
+
+struct LossArgs {
+    const float *y, *g, *normals, *sdf;     // y [np], g [np][4], normals (n,3), sdf (n)
+    float *ybar, *gbar;
+    const float* cot;                        // device, 4 floats
+    const double* stats;                     // device, 3 doubles (s2)
+    double* acc;                             // device, >= 4 doubles
+    int64_t n, np;
+    float w[4];
+    float alpha, inv_n;                      // 1 / n_global
+};
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+// per-point pieces of loss_s1 (reference src/loss_functions.py:131-136, :9-22)
+__device__ __forceinline__ void s1_point(float y, const f32x4 g, float u, float alpha,
+                                         float& t_on, float& t_off, float& t_g, float& tdf, float& gn, float& tau) {
+    const float tn = tanhf(alpha * u);
+    tdf = u * tn;
+    const bool on = (u == 0.f);
+    t_on = on ? fabsf(y) : 0.f;
+    t_off = on ? 0.f : fabsf(tdf - y);
+    gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    tau = fabsf(tn + u * alpha * (1.f - tn * tn));
+    t_g = fabsf(gn - tau);
+}
+
+// mode 0: loss_s1 (Hessian weight must be 0), mode 2: loss_siren (reference :82-104, :24-32)
+template <int MODE>
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
+    double v[4] = {0, 0, 0, 0};
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * blockDim.x) {
+        const float y = a.y[p];
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + p * 4);
+        const float u = a.sdf[p];
+        if constexpr (MODE == DUDF_LOSS_S1) {
+            float t_on, t_off, t_g, tdf, gn, tau;
+            s1_point(y, g, u, a.alpha, t_on, t_off, t_g, tdf, gn, tau);
+            v[0] += t_on; v[1] += t_off;
+            if (a.w[3] != 0.f) v[3] += t_g;
+        } else {
+            const bool on = (u == 0.f);
+            const float ay = fabsf(y);
+            const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            v[0] += on ? ay : 0.f;
+            v[1] += on ? 0.f : expf(-100.f * ay);
+            if (on) {
+                const float m0 = a.normals[p * 3], m1 = a.normals[p * 3 + 1], m2 = a.normals[p * 3 + 2];
+                const float mn = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+                const float cs = (g[0] * m0 + g[1] * m1 + g[2] * m2) / (fmaxf(gn, 1e-8f) * fmaxf(mn, 1e-8f));
+                v[2] += 1.f - cs;
+            }
+            v[3] += (gn - 1.f) * (gn - 1.f);
+        }
+    }
+    block_accumulate<4>(v, a.acc);
+}
+
+__global__ void loss_finalize_kernel(const double* acc, float* out, double w0, double w1, double w2, double w3,
+                                     double inv_n) {
+    if (threadIdx.x == 0) {
+        out[0] = (float)(acc[0] * inv_n * w0);
+        out[1] = (float)(acc[1] * inv_n * w1);
+        out[2] = (float)(acc[2] * inv_n * w2);
+        out[3] = (float)(acc[3] * inv_n * w3);
+    }
+}
+
+// cotangents ybar (on y) and gbar (on df/dx) of  sum_i cot[i] * term_i   
+template <int MODE>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
+    const float c0 = a.cot[0], c1 = a.cot[1], c2 = (MODE == DUDF_LOSS_S2) ? 0.f : a.cot[2],
+                c3 = (MODE == DUDF_LOSS_S2) ? 0.f : a.cot[3];
+    double mu = 0, sd = 1, cnt = 2;
+    if constexpr (MODE == DUDF_LOSS_S2) {
+        cnt = a.stats[0];
+        mu = a.stats[1] / cnt;
+        sd = sqrt((a.stats[2] - cnt * mu * mu) / (cnt - 1.0));
+    }
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.np; p += (int64_t)gridDim.x * blockDim.x) {
+        float yb = 0.f;
+        f32x4 gb = {0, 0, 0, 0};
+        if (p < a.n) {
+            const float y = a.y[p];
+            const float u = a.sdf[p];
+            const bool on = (u == 0.f);
+            if constexpr (MODE == DUDF_LOSS_S1) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + p * 4);
+                float t_on, t_off, t_g, tdf, gn, tau;
+                s1_point(y, g, u, a.alpha, t_on, t_off, t_g, tdf, gn, tau);
+                yb = on ? c0 * a.w[0] * a.inv_n * sgn(y) : -c1 * a.w[1] * a.inv_n * sgn(tdf - y);
+                if (a.w[3] != 0.f && gn > 0.f) {
+                    const float k = c3 * a.w[3] * a.inv_n * sgn(gn - tau) / gn;
+                    gb = f32x4{k * g[0], k * g[1], k * g[2], 0.f};
+                }
+            } else if constexpr (MODE == DUDF_LOSS_SIREN) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + p * 4);
+                const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                yb = on ? c0 * a.w[0] * a.inv_n * sgn(y)
+                        : -c1 * a.w[1] * a.inv_n * 100.f * sgn(y) * expf(-100.f * fabsf(y));
+                float k = (gn > 0.f) ? c3 * a.w[3] * a.inv_n * 2.f * (gn - 1.f) / gn : 0.f;
+                gb = f32x4{k * g[0], k * g[1], k * g[2], 0.f};
+                if (on) {
+                    const float m0 = a.normals[p * 3], m1 = a.normals[p * 3 + 1], m2 = a.normals[p * 3 + 2];
+                    const float mn = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+                    const float gnc = fmaxf(gn, 1e-8f), mnc = fmaxf(mn, 1e-8f);
+                    const float cs = (g[0] * m0 + g[1] * m1 + g[2] * m2) / (gnc * mnc);
+                    const float ka = -c2 * a.w[2] * a.inv_n;
+                    const float k1 = ka / (gnc * mnc);
+                    const float k2 = (gn > 1e-8f) ? ka * cs / (gnc * gnc) : 0.f;
+                    gb[0] += k1 * m0 - k2 * g[0];
+                    gb[1] += k1 * m1 - k2 * g[1];
+                    gb[2] += k1 * m2 - k2 * g[2];
+                }
+            } else {                                     // loss_s2 (reference :106-121)
+                if (on) {
+                    const double smu = (mu > 0) ? 1.0 : ((mu < 0) ? -1.0 : 0.0);
+                    yb = (float)((double)c0 * a.w[0] * smu / cnt + (double)c1 * a.w[1] * ((double)y - mu) / ((cnt - 1.0) * sd));
+                }
+            }
+        }
+        a.ybar[p] = yb;
+        *reinterpret_cast<f32x4*>(a.gbar + p * 4) = gb;
+    }
+}
+
+__global__ __launch_bounds__(256) void s2_stats_kernel(const float* __restrict__ y, const float* __restrict__ sdf,
+                                                       int64_t n, double* __restrict__ stats) {
+    double v[3] = {0, 0, 0};
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (sdf[p] == 0.f) {
+            const double yy = y[p];
+            v[0] += 1.0; v[1] += yy; v[2] += yy * yy;
+        }
+    }
+    block_accumulate<3>(v, stats);
+}
+
+__global__ void s2_terms_kernel(const double* stats, double w0, double w1, float* out) {
+    if (threadIdx.x == 0) {
+        const double cnt = stats[0], mu = stats[1] / cnt;
+        const double var = (stats[2] - cnt * mu * mu) / (cnt - 1.0);
+        out[0] = (float)(fabs(mu) * w0);
+        out[1] = (float)(sqrt(var > 0 ? var : 0.0) * w1);
+    }
+}
+
+// ---- Adam (torch.optim.Adam single-tensor semantics, reference train.py:334-337) -------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                                                   float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // lerp, as torch does
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        theta[i] = theta[i] - step_size * (mi / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void read_stash_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                         int64_t n, int64_t np, int H) {
+    const int64_t tot = n * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / H; const int f = (int)(i % H);
+        out[i] = src[((int64_t)(f >> 2) * np + p) * 4 + (f & 3)];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_out_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                       float* __restrict__ of, float* __restrict__ og, int64_t n) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (of) of[p] = y[p];
+        if (og) { og[p * 3] = g[p * 4]; og[p * 3 + 1] = g[p * 4 + 1]; og[p * 3 + 2] = g[p * 4 + 2]; }
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+LossArgs make_loss_args(const DudfLayout& lo, const float* normals, const float* sdf, int64_t n_global,
+                        const double* w, double alpha, float* ws) {
+    LossArgs a;
+    a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.normals = normals; a.sdf = sdf;
+    a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar; a.cot = nullptr; a.stats = nullptr;
+    a.acc = reinterpret_cast<double*>(ws + lo.ws_acc);
+    a.n = lo.n; a.np = lo.np;
+    for (int i = 0; i < 4; ++i) a.w[i] = (float)w[i];
+    a.alpha = (float)alpha; a.inv_n = (float)(1.0 / (double)n_global);
+    return a;
+}
+
+}  // namespace
+
+int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
+    int64_t n = (int64_t)(lo.L - 1) * lo.H * lo.H;
+    if (n < 16 * (int64_t)lo.H) n = 16 * (int64_t)lo.H;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, ws + lo.ws_w1b,
+                       ws + lo.ws_w1t16, ws + lo.ws_wt, lo.H, lo.L, lo.off_hid, lo.hid_stride);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
+                         const double* w, double alpha, float* ws, float* out_terms, hipStream_t st) {
+    LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
+    hipError_t e = hipMemsetAsync(a.acc, 0, 4 * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+    const int grid = grid_for(lo.n);
+    if (mode == DUDF_LOSS_S1) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_S1>, dim3(grid), dim3(256), 0, st, a);
+    else if (mode == DUDF_LOSS_SIREN) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_SIREN>, dim3(grid), dim3(256), 0, st, a);
+    else return DUDF_E_BADMODE;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a.acc, out_terms, w[0], w[1], w[2], w[3],
+                       1.0 / (double)n_global);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
+                         const double* w, double alpha, const float* cot, const double* stats, float* ws,
+                         hipStream_t st) {
+    LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
+    a.cot = cot; a.stats = stats;
+    const int grid = grid_for(lo.np);
+    if (mode == DUDF_LOSS_S1) hipLaunchKernelGGL(loss_bwd_kernel<DUDF_LOSS_S1>, dim3(grid), dim3(256), 0, st, a);
+    else if (mode == DUDF_LOSS_SIREN) hipLaunchKernelGGL(loss_bwd_kernel<DUDF_LOSS_SIREN>, dim3(grid), dim3(256), 0, st, a);
+    else if (mode == DUDF_LOSS_S2) hipLaunchKernelGGL(loss_bwd_kernel<DUDF_LOSS_S2>, dim3(grid), dim3(256), 0, st, a);
+    else return DUDF_E_BADMODE;
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, double* stats, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(stats, 0, 3 * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(s2_stats_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, sdf, lo.n, stats);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms, hipStream_t st) {
+    hipLaunchKernelGGL(s2_terms_kernel, dim3(1), dim3(64), 0, st, stats, w[0], w[1], out_terms);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+                     double eps, int64_t step, double gscale, hipStream_t st) {
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, theta, g, m, v, n, (float)b1, (float)b2,
+                       (float)eps, (float)(lr / bc1), (float)sqrt(bc2), (float)gscale);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(read_stash_kernel, dim3(grid_for(lo.n * lo.H)), dim3(256), 0, st,
+                       src + (int64_t)layer * lo.stash_layer, out, lo.n, lo.np, lo.H);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, hipStream_t st) {
+    hipLaunchKernelGGL(copy_out_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, ws + lo.ws_g, out_f,
+                       out_g, lo.n);
+    return (int)hipGetLastError();
+}

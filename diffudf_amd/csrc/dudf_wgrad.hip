@@ -1,0 +1,292 @@
+// Weight gradients of the DiffUDF training step: the part of `train_loss.backward()` (reference
+// train.py:221) that contracts over POINTS.  SURVEY.md Appendix A.5:
+//
+//   dW_l[o][i] = sum_p  q_l[o][p] * A_{l-1}[i][p]  +  zbar_l[o][p] * s_{l-1}[i][p]        (l = 2..L)
+//   db_l[o]    = sum_p  zbar_l[o][p]
+//   dW_1[o][d] = sum_p  q_1[o][p] * gbar[p][d]  +  zbar_1[o][p] * x[p][d] ;  db_1 = sum_p zbar_1
+//   dW_out[f]  = sum_p  A_L[f][p] + ybar[p] * s_L[f][p] ;                     db_out = sum_p ybar
+//
+// The sweeps leave q, A, zbar, s in HBM as [layer][feature/4][point][4] (dudf_internal.h).  That is
+// the K-major layout a GEMM whose K dimension is the point index wants, so the hidden layers are one
+// v_mfma_f32_32x32x2_f32 GEMM per layer (M = N = H, K = 2*n points) split over point ranges:
+// a workgroup owns the whole HxH tile of one layer for a range of points, stages 32 points of the two
+// operands through LDS per step ([fq][33][4] floats: the 33 makes the per-feature b32 reads
+// conflict-free), and adds its partial tile into dtheta with float atomics at the end (each atomic
+// wave-instruction is two 128-byte row segments — the full-rate shape; 256 KB per workgroup).
+// The bias gradient rides along as one extra MFMA per A fragment against a B operand of ones.
+// The two thin layers (3 inputs / 1 output) are a bandwidth-bound VALU reduction.
+#include "dudf_internal.h"
+
+namespace {
+
+template <int H> struct WG;
+template <> struct WG<256> { static constexpr int WO = 4, WI = 2, MT = 2, NTL = 4; };
+template <> struct WG<128> { static constexpr int WO = 4, WI = 2, MT = 1, NTL = 2; };
+template <> struct WG<64>  { static constexpr int WO = 2, WI = 2, MT = 1, NTL = 1; };
+template <> struct WG<32>  { static constexpr int WO = 1, WI = 1, MT = 1, NTL = 1; };
+
+constexpr int KT = 32;          // points per LDS stage
+constexpr int KTP = 33;         // padded
+
+struct WgradArgs {
+    const float *Q, *A, *Z, *S;         // stash arrays
+    float* dtheta;
+    int64_t np, stash_layer, off_hid, hid_stride;
+    int steps_total;                    // np / KT
+    int L;
+    int have_g;                         // 0: loss without df/dx terms (loss_s2) -> only the zbar*s pair
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kernel(WgradArgs a) {
+    using W = WG<H>;
+    constexpr int NTHR = 64 * W::WO * W::WI;
+    constexpr int FQ = H / 4;                       // feature quads per operand
+    constexpr int TILE = FQ * KTP * 4;              // floats per staged operand
+    constexpr int F4 = FQ * KT;                     // float4 per operand per stage
+    constexpr int NLD = (F4 + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsX = lds;
+    float* ldsY = lds + TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = wave / W::WI, wi = wave % W::WI;
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int j = blockIdx.x;                       // hidden matrix index: layer l = j + 2
+    const int nsplit = gridDim.y;
+    const int s0 = (int)((int64_t)a.steps_total * blockIdx.y / nsplit);
+    const int s1 = (int)((int64_t)a.steps_total * (blockIdx.y + 1) / nsplit);
+
+    f32x16 acc[W::MT][W::NTL];
+    f32x16 accb[W::MT];
+#pragma unroll
+    for (int m = 0; m < W::MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < W::NTL; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[m][e] = 0.f;
+    }
+
+    // pair 0: X = q_l (layer index j+1), Y = A_{l-1} (index j);  pair 1: X = zbar_l, Y = s_{l-1}
+    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer;
+    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer;
+    const float* Y0 = a.A + (int64_t)j * a.stash_layer;
+    const float* Y1 = a.S + (int64_t)j * a.stash_layer;
+
+    f32x4 rx[NLD], ry[NLD];
+    auto issue = [&](int pair, int step) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int f = tid + NTHR * u;
+            if (f < F4) {
+                const int fq = f / KT, pt = f % KT;
+                const int64_t off = ((int64_t)fq * a.np + (int64_t)step * KT + pt) * 4;
+                rx[u] = *reinterpret_cast<const f32x4*>((pair ? X1 : X0) + off);
+                ry[u] = *reinterpret_cast<const f32x4*>((pair ? Y1 : Y0) + off);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int f = tid + NTHR * u;
+            if (f < F4) {
+                const int fq = f / KT, pt = f % KT;
+                *reinterpret_cast<f32x4*>(ldsX + (fq * KTP + pt) * 4) = rx[u];
+                *reinterpret_cast<f32x4*>(ldsY + (fq * KTP + pt) * 4) = ry[u];
+            }
+        }
+    };
+
+    const int npair = a.have_g ? 2 : 1;
+    const int nit = npair * (s1 - s0);              // (step, pair) iterations
+    auto pair_of = [&](int it) { return a.have_g ? (it & 1) : 1; };
+    auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
+    if (nit > 0) issue(pair_of(0), step_of(0));
+    for (int it = 0; it < nit; ++it) {
+        const int pair = pair_of(it);
+        __syncthreads();                            // previous stage fully consumed
+        commit();
+        __syncthreads();
+        if (it + 1 < nit) issue(pair_of(it + 1), step_of(it + 1));
+        // feature row of this lane inside the operand tiles
+        const float* xa[W::MT];
+        const float* yb[W::NTL];
+#pragma unroll
+        for (int m = 0; m < W::MT; ++m) {
+            const int feat = (wo * W::MT + m) * 32 + l32;
+            xa[m] = ldsX + ((feat >> 2) * KTP) * 4 + (feat & 3);
+        }
+#pragma unroll
+        for (int n = 0; n < W::NTL; ++n) {
+            const int feat = (wi * W::NTL + n) * 32 + l32;
+            yb[n] = ldsY + ((feat >> 2) * KTP) * 4 + (feat & 3);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; ++kk) {
+            const int pt = 2 * kk + hh;             // MFMA k index = lane>>5
+            float av[W::MT], bv[W::NTL];
+#pragma unroll
+            for (int m = 0; m < W::MT; ++m) av[m] = xa[m][pt * 4];
+#pragma unroll
+            for (int n = 0; n < W::NTL; ++n) bv[n] = yb[n][pt * 4];
+#pragma unroll
+            for (int m = 0; m < W::MT; ++m) {
+#pragma unroll
+                for (int n = 0; n < W::NTL; ++n) acc[m][n] = mfma32(av[m], bv[n], acc[m][n]);
+                if (pair == 1 && wi == 0) accb[m] = mfma32(av[m], 1.0f, accb[m]);
+            }
+        }
+    }
+
+    // D layout 32x32: col = lane&31 (input index i), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output index o)
+    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride;
+    float* dB = dW + (int64_t)H * H;
+    if (nit > 0) {
+#pragma unroll
+        for (int m = 0; m < W::MT; ++m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int o = (wo * W::MT + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+                for (int n = 0; n < W::NTL; ++n) {
+                    const int i = (wi * W::NTL + n) * 32 + l32;
+                    atomicAdd(dW + (int64_t)o * H + i, acc[m][n][e]);
+                }
+                if (wi == 0 && l32 == 0) atomicAdd(dB + o, accb[m][e]);
+            }
+        }
+    }
+}
+
+// ---- first and last layer: thin reductions over points (bandwidth-bound, VALU) -------------------------
+struct WgradSmallArgs {
+    const float *Q, *A, *Z, *S;
+    const float *x, *gbar, *ybar;       // x (n,3); gbar [np][4]; ybar [np]
+    float* dtheta;
+    int64_t n, np, stash_layer, off_wo, off_bo;
+    int H, L, have_g;
+    int pts_per_block;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// grid.x = point ranges; block = 256 threads = 4 waves; each wave loops over feature quads,
+// lanes run over 64 consecutive points (16-byte granules -> 1 KiB coalesced per load).
+__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int FQ = a.H / 4;
+    const int64_t p0 = (int64_t)blockIdx.x * a.pts_per_block;
+    const int64_t p1 = (p0 + a.pts_per_block < a.np) ? p0 + a.pts_per_block : a.np;
+    const float* Q0 = a.Q;                                          // layer index 0
+    const float* Z0 = a.Z;
+    const float* AL = a.A + (int64_t)(a.L - 1) * a.stash_layer;
+    const float* SL = a.S + (int64_t)(a.L - 1) * a.stash_layer;
+    for (int fq = wave; fq < FQ; fq += 4) {
+        float w1[4][3], b1[4], wo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b1[c] = 0.f; wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = 0.f; }
+        for (int64_t p = p0 + lane; p < p1; p += 64) {
+            const int64_t off = ((int64_t)fq * a.np + p) * 4;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(Z0 + off);
+            const f32x4 sl = *reinterpret_cast<const f32x4*>(SL + off);
+            const float yb = a.ybar[p];
+            float xv[3] = {0.f, 0.f, 0.f};
+            if (p < a.n) { xv[0] = a.x[p * 3]; xv[1] = a.x[p * 3 + 1]; xv[2] = a.x[p * 3 + 2]; }
+            f32x4 qv = {0, 0, 0, 0}, al = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
+            if (a.have_g) {
+                qv = *reinterpret_cast<const f32x4*>(Q0 + off);
+                al = *reinterpret_cast<const f32x4*>(AL + off);
+                gb = *reinterpret_cast<const f32x4*>(a.gbar + p * 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) w1[c][d] += qv[c] * gb[d] + z[c] * xv[d];
+                b1[c] += z[c];
+                wo[c] += al[c] + yb * sl[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = 4 * fq + c;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = wave_sum(w1[c][d]);
+                if (lane == 0) atomicAdd(a.dtheta + f * 3 + d, v);
+            }
+            const float vb = wave_sum(b1[c]);
+            const float vo = wave_sum(wo[c]);
+            if (lane == 0) {
+                atomicAdd(a.dtheta + 3 * a.H + f, vb);
+                atomicAdd(a.dtheta + a.off_wo + f, vo);
+            }
+        }
+    }
+    if (wave == 0) {                                                  // db_out = sum ybar
+        float s = 0.f;
+        for (int64_t p = p0 + lane; p < p1; p += 64) s += a.ybar[p];
+        s = wave_sum(s);
+        if (lane == 0) atomicAdd(a.dtheta + a.off_bo, s);
+    }
+}
+
+template <int H>
+int launch_hidden(const WgradArgs& a, hipStream_t st) {
+    using W = WG<H>;
+    constexpr int NTHR = 64 * W::WO * W::WI;
+    const size_t smem = 2 * (size_t)(H / 4) * KTP * 4 * sizeof(float);
+    const int nl = a.L - 1;
+    if (nl <= 0) return 0;
+    int nsplit = (512 + nl - 1) / nl;                    // ~2 workgroups per CU across the layers
+    if (nsplit > a.steps_total) nsplit = a.steps_total;
+    if (nsplit < 1) nsplit = 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_kernel<H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit), dim3(NTHR), smem, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dtheta, int have_g, hipStream_t st) {
+    WgradArgs a;
+    a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S;
+    a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
+    a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.np / KT); a.L = lo.L;
+    a.have_g = have_g;
+    int rc = 0;
+    {
+        switch (lo.H) {
+            case 32: rc = launch_hidden<32>(a, st); break;
+            case 64: rc = launch_hidden<64>(a, st); break;
+            case 128: rc = launch_hidden<128>(a, st); break;
+            case 256: rc = launch_hidden<256>(a, st); break;
+            default: return DUDF_E_BADCFG;
+        }
+    }
+    if (rc) return rc;
+    WgradSmallArgs s;
+    s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x = x; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
+    s.dtheta = dtheta; s.n = lo.n; s.np = lo.np; s.stash_layer = lo.stash_layer;
+    s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
+    s.pts_per_block = 512;
+    const int grid = (int)((lo.np + s.pts_per_block - 1) / s.pts_per_block);
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid), dim3(256), 0, st, s);
+    return (int)hipGetLastError();
+}

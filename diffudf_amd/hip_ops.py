@@ -1,0 +1,146 @@
+# coding: utf-8
+"""Thin torch-facing layer over the C ABI: device pointers + the current HIP stream.
+
+PyTorch is plumbing here (device memory, streams); every number is produced by the
+hand-written HIP kernels in diffudf_amd/csrc.  No function in this module has a CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import NetCfg, LOSS_S1, LOSS_S2, LOSS_SIREN  # noqa: F401
+
+
+def make_cfg(hidden, w0=30.0, n_in=3, n_out=1):
+    hidden = list(hidden)
+    if n_in != 3 or n_out != 1 or len(hidden) < 1 or any(h != hidden[0] for h in hidden):
+        raise _lib.DudfError("HIP path supports SIREN(3, 1, [H]*L) with equal hidden widths; got "
+                             f"n_in={n_in}, n_out={n_out}, hidden={hidden}")
+    return NetCfg(3, len(hidden), int(hidden[0]), float(w0))
+
+
+def theta_count(cfg):
+    n = _lib.load().dudf_theta_count(ctypes.byref(cfg))
+    if n < 0:
+        _lib.check(-1, "dudf_theta_count")
+    return int(n)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, what):
+    if t.device.type != "cuda":
+        raise _lib.DudfError(f"{what} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Workspace:
+    """Caller-owned scratch for one (cfg, n_points).  Holds the stash between forward and backward."""
+
+    def __init__(self, cfg, n, device):
+        self.cfg, self.n = cfg, int(n)
+        self.nbytes = int(_lib.load().dudf_workspace_bytes(ctypes.byref(cfg), self.n))
+        if self.nbytes == 0:
+            _lib.check(-1, "dudf_workspace_bytes")
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        assert self.buf.data_ptr() % 16 == 0
+
+
+_ws_cache = {}
+
+
+def workspace_for(cfg, n, device):
+    key = (cfg.n_hidden_layers, cfg.hidden, cfg.w0, int(n), str(device))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        for k in [k for k in _ws_cache if k[:3] == key[:3] and k[4] == key[4]]:
+            del _ws_cache[k]                      # one live workspace per network: they are large
+        ws = _ws_cache[key] = Workspace(cfg, n, device)
+    return ws
+
+
+def query(cfg, theta, x, want_grad=True, ws=None):
+    """f (n,), df/dx (n,3) or None.  Reference: src/evaluate.py:26-32 per chunk."""
+    lib = _lib.load()
+    x = _f32(x, "x").view(-1, 3)
+    theta = _f32(theta, "theta")
+    n = x.shape[0]
+    ws = ws or workspace_for(cfg, n, x.device)
+    f = torch.empty(n, dtype=torch.float32, device=x.device)
+    g = torch.empty(n, 3, dtype=torch.float32, device=x.device) if want_grad else None
+    rc = lib.dudf_query(ctypes.byref(cfg), _ptr(theta), _ptr(x), n, _ptr(f), _ptr(g), _ptr(ws.buf), ws.nbytes,
+                        _stream())
+    _lib.check(rc, "dudf_query")
+    return f, g
+
+
+def _w4(weights):
+    w = list(weights) + [0.0] * (4 - len(weights))
+    return (ctypes.c_double * 4)(*[float(v) for v in w])
+
+
+def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws):
+    lib = _lib.load()
+    n = x.shape[0]
+    terms = torch.empty(4, dtype=torch.float32, device=x.device)
+    rc = lib.dudf_loss_forward(ctypes.byref(cfg), mode, _ptr(theta), _ptr(x), _ptr(normals), _ptr(sdf), n,
+                               int(n_global), _w4(weights), float(alpha), _ptr(terms), _ptr(ws.buf), ws.nbytes,
+                               _stream())
+    _lib.check(rc, "dudf_loss_forward")
+    return terms
+
+
+def s2_forward_stats(cfg, theta, x, sdf, ws):
+    lib = _lib.load()
+    stats = torch.empty(3, dtype=torch.float64, device=x.device)
+    rc = lib.dudf_s2_forward_stats(ctypes.byref(cfg), _ptr(theta), _ptr(x), _ptr(sdf), x.shape[0], _ptr(stats),
+                                   _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_s2_forward_stats")
+    return stats
+
+
+def s2_terms(stats, weights):
+    lib = _lib.load()
+    terms = torch.empty(2, dtype=torch.float32, device=stats.device)
+    rc = lib.dudf_s2_terms(_ptr(stats), _w4(weights), _ptr(terms), _stream())
+    _lib.check(rc, "dudf_s2_terms")
+    return terms
+
+
+def loss_backward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot, stats, ws, dtheta=None,
+                  accumulate=False):
+    lib = _lib.load()
+    if dtheta is None:
+        dtheta = torch.empty_like(theta)
+        accumulate = False
+    rc = lib.dudf_loss_backward(ctypes.byref(cfg), mode, _ptr(theta), _ptr(x), _ptr(normals), _ptr(sdf), x.shape[0],
+                                int(n_global), _w4(weights), float(alpha), _ptr(cot), _ptr(stats), _ptr(dtheta),
+                                1 if accumulate else 0, _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_loss_backward")
+    return dtheta
+
+
+def adam_step(theta, dtheta, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    lib = _lib.load()
+    rc = lib.dudf_adam_step(_ptr(theta), _ptr(dtheta), _ptr(exp_avg), _ptr(exp_avg_sq), theta.numel(), float(lr),
+                            float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+    _lib.check(rc, "dudf_adam_step")
+
+
+def read_stash(cfg, which, layer, n, ws):
+    """Diagnostic: (n,H) copy of one stashed quantity ('s','c','q','e','A','zbar') of hidden layer `layer`."""
+    lib = _lib.load()
+    idx = {"s": 0, "c": 1, "q": 2, "e": 3, "r": 3, "A": 4, "zbar": 5}[which]
+    out = torch.empty(n, cfg.hidden, dtype=torch.float32, device=ws.buf.device)
+    rc = lib.dudf_debug_read_stash(ctypes.byref(cfg), idx, layer, n, _ptr(out), _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_debug_read_stash")
+    return out

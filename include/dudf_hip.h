@@ -1,0 +1,108 @@
+/* dudf_hip.h — C ABI of the MI355X-native DiffUDF training hot path (libdudf_hip.so).
+ *
+ * The reference (LIA-DiTella/DiffUDF) has no FFI: its hot path is a Python-level operator
+ * API on PyTorch autograd.  Each entry point below names the reference interface it replaces
+ * (file:line in the reference tree); the Python mirror in diffudf_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless it says "host";
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - no allocation inside: the caller passes a workspace of dudf_workspace_bytes() bytes,
+ *     16-byte aligned, and must leave it untouched between a *_forward and its *_backward;
+ *   - return value: 0 = ok, >0 = hipError_t of a failed launch, <0 = DUDF_E_* below;
+ *   - theta = flat fp32 parameters in the reference's state_dict order
+ *     (net.0.0.weight (H,3) row-major, net.0.0.bias (H), net.1.0.weight (H,H), ...,
+ *      net.L.0.weight (1,H), net.L.0.bias (1))  — reference src/model.py:94-113;
+ *   - points are fp32: x (n,3) row-major, normals (n,3), sdf (n) — the tensors
+ *     reference src/dataset.py:170-185 yields (without their leading batch-of-1 axis).
+ */
+#ifndef DUDF_HIP_H
+#define DUDF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUDF_E_BADCFG   (-1)   /* unsupported network shape (hidden widths must be equal, in {32,64,128,256}) */
+#define DUDF_E_WORKSPACE (-2)  /* workspace too small / misaligned */
+#define DUDF_E_BADMODE  (-3)
+#define DUDF_E_UNSUPPORTED (-4) /* e.g. loss_s1 with a non-zero Hessian weight: not built yet */
+
+/* loss selector — reference src/loss_functions.py:123 (loss_s1), :106 (loss_s2), :82 (loss_siren) */
+#define DUDF_LOSS_S1    0
+#define DUDF_LOSS_S2    1
+#define DUDF_LOSS_SIREN 2
+
+typedef struct dudf_net_cfg {
+    int32_t n_in;            /* 3 */
+    int32_t n_hidden_layers; /* L = len(hidden_layer_config), reference src/model.py:94-108 */
+    int32_t hidden;          /* H, all hidden layers equal */
+    float   w0;              /* SineLayer frequency, reference src/model.py:25-30 (ww == w0) */
+} dudf_net_cfg;
+
+/* number of floats in theta for this cfg (461 825 for 8x256) */
+int64_t dudf_theta_count(const dudf_net_cfg* cfg);
+
+/* bytes of workspace needed for a local batch of n points (training: stash of all sweeps) */
+size_t dudf_workspace_bytes(const dudf_net_cfg* cfg, int64_t n);
+
+/* Replaces `model(x)['model_out']` + `gradient(y, x)` as used by the chunk loop of
+ * reference src/evaluate.py:26-35 (SIREN.forward src/model.py:116-135; gradient
+ * src/diff_operators.py:208-212).  out_f (n); out_g (n,3) or NULL for value only. */
+int dudf_query(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+               float* out_f, float* out_g, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Forward half of loss_s1 / loss_siren (reference src/loss_functions.py:123-155, :82-104):
+ * SIREN forward, df/dx, the four weighted loss terms.  out_terms (device, 4 floats) receives
+ * THIS RANK's share  sum_local(term_i) * weight / n_global  in the reference's dict order
+ * (s1: sdf_on_surf, sdf_off_surf, hessian_constraint, grad_constraint;
+ *  siren: sdf_on_surf, sdf_off_surf, normal_constraint, grad_constraint).
+ * weights: host, 4 doubles.  The activations needed by dudf_loss_backward stay in `workspace`. */
+int dudf_loss_forward(const dudf_net_cfg* cfg, int mode, const float* theta,
+                      const float* x, const float* normals, const float* sdf,
+                      int64_t n_local, int64_t n_global, const double* weights, double alpha,
+                      float* out_terms, void* workspace, size_t workspace_bytes, void* stream);
+
+/* loss_s2 (reference src/loss_functions.py:106-121) needs the mean/std of the on-surface
+ * predictions over the GLOBAL batch, so its forward is split in two:
+ *   dudf_s2_forward_stats: SIREN forward, writes (count, sum, sum of squares) of y over this
+ *       rank's on-surface points to stats (device, 3 doubles) — all-reduce(sum) them across ranks;
+ *   dudf_s2_terms: out_terms[0] = |mean|*w0, out_terms[1] = std_unbiased*w1 (device, 2 floats),
+ *       from the (all-reduced) stats. */
+int dudf_s2_forward_stats(const dudf_net_cfg* cfg, const float* theta, const float* x, const float* sdf,
+                          int64_t n_local, double* stats, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int dudf_s2_terms(const double* stats, const double* weights, float* out_terms, void* stream);
+
+/* Replaces `train_loss.backward()` (reference train.py:212-221) for the loss whose forward was
+ * the last dudf_loss_forward / dudf_s2_forward_stats on this workspace.  cot (device, 4 floats;
+ * 2 used for s2) = upstream gradient of each returned term (all ones in the reference loop).
+ * dtheta (theta-sized, device) is overwritten when accumulate == 0, added to otherwise.
+ * stats: device, 3 doubles (s2 only, else NULL). */
+int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta,
+                       const float* x, const float* normals, const float* sdf,
+                       int64_t n_local, int64_t n_global, const double* weights, double alpha,
+                       const float* cot, const double* stats, float* dtheta, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam.step() with default betas/eps semantics (reference train.py:334-337, :222) on
+ * flat buffers.  step = 1-based count after this update.  grad_scale multiplies the gradient
+ * first (1/world_size after an all-reduce(sum) is NOT needed here: ranks hold shares of one mean). */
+int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
+                   void* stream);
+
+/* Test/diagnostic hook: copy one stashed per-layer quantity of the last sweep into out (n,H) row-major.
+ * which: 0 s_l, 1 c_l, 2 q_l, 3 e_l (r_l before backward), 4 A_l, 5 zbar_l; layer: 0-based hidden layer. */
+int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t n,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* library / build identification, host string */
+const char* dudf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUDF_HIP_H */

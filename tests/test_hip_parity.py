@@ -1,0 +1,168 @@
+# coding: utf-8
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Tolerances (relative to the max-norm of the reference quantity) follow the fp32 noise floor of the
+reference itself against its own fp64 run (re-measured in
+tests/test_oracle_golden.py::test_g2_8x256_fields_and_grads):
+    value 5e-6, df/dx 2e-5, loss terms 1e-5, parameter gradient 1e-4 (Eikonal path).
+"""
+import os
+import numpy as np
+import pytest
+import torch
+
+from diffudf_amd import synth
+from oracle import dudf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_F, TOL_G, TOL_TERM, TOL_DTHETA = 5e-6, 2e-5, 1e-5, 1e-4
+W_S1EIK = [1e4, 1e4, 0.0, 1e3]
+W_S2 = [1e5, 1e5]
+W_SIREN = [3e3, 1e2, 1e2, 5e1]
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def flat(grads):
+    return np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from diffudf_amd import hip_ops
+    return hip_ops
+
+
+def setup(hidden, n, seed):
+    P32 = synth.siren_params(hidden, seed=seed, dtype=np.float32)
+    theta = synth.flatten_params(P32)
+    x, nrm, sdf = synth.training_batch(n, seed=seed, dtype=np.float32)
+    P64 = [(w.astype(np.float64), b.astype(np.float64)) for w, b in P32]
+    return P64, theta, x, nrm, sdf
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+NETS = [([32, 32, 32], 63, 7), ([64] * 4, 200, 11), ([128] * 3, 130, 5), ([256] * 8, 1000, 123)]
+
+
+@pytest.mark.parametrize("hidden,n,seed", NETS)
+def test_query_value_and_gradient(hip, hidden, n, seed):
+    P, theta, x, _, _ = setup(hidden, n, seed)
+    cfg = hip.make_cfg(hidden)
+    f, g = hip.query(cfg, dev(theta), dev(x), want_grad=True)
+    y_ref, g_ref, _ = O.query(P, x.astype(np.float64))
+    ef, eg = rel(f.cpu().numpy(), y_ref), rel(g.cpu().numpy(), g_ref)
+    print(f"query {hidden[0]}x{len(hidden)} n={n}: f {ef:.2e} g {eg:.2e}")
+    assert ef < TOL_F and eg < TOL_G
+    f2, g2 = hip.query(cfg, dev(theta), dev(x), want_grad=False)
+    assert g2 is None and rel(f2.cpu().numpy(), y_ref) < TOL_F
+
+
+@pytest.mark.parametrize("hidden,n,seed", NETS)
+@pytest.mark.parametrize("case,mode,w", [("s1eik", "s1", W_S1EIK), ("siren", "siren", W_SIREN)])
+def test_loss_and_parameter_gradient(hip, hidden, n, seed, case, mode, w):
+    P, theta, x, nrm, sdf = setup(hidden, n, seed)
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda")
+    m = {"s1": hip.LOSS_S1, "siren": hip.LOSS_SIREN}[mode]
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    terms = hip.loss_forward(cfg, m, th, xd, nd, sd, n, w, 100.0, ws)
+    t_ref, g_ref, dbg = O.loss_and_grad(mode, P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), w, 100.0)
+    t_ref = np.array([float(v) for v in t_ref.values()])
+    # stage-by-stage: what the forward sweeps stashed
+    L = len(hidden)
+    for l in range(L):
+        for name, ref in (("s", dbg["cache"]["s"][l]), ("c", dbg["cache"]["c"][l]), ("q", dbg["rev"]["q"][l])):
+            got = hip.read_stash(cfg, name, l, n, ws).cpu().numpy()
+            e = rel(got, ref)
+            assert e < 5e-5, f"{case} stash {name}[{l}] rel err {e:.2e}"
+    et = rel(terms.cpu().numpy(), t_ref)
+    cot = torch.ones(4, device="cuda")
+    dth = hip.loss_backward(cfg, m, th, xd, nd, sd, n, w, 100.0, cot, None, ws)
+    for l in range(L):
+        for name, ref in (("A", dbg["trace"]["A"][l]), ("e", dbg["trace"]["e"][l]), ("zbar", dbg["trace"]["zbar"][l])):
+            got = hip.read_stash(cfg, name, l, n, ws).cpu().numpy()
+            e = rel(got, ref)
+            assert e < 2e-4, f"{case} stash {name}[{l}] rel err {e:.2e}"
+    ed = rel(dth.cpu().numpy(), flat(g_ref))
+    print(f"{case} {hidden[0]}x{L} n={n}: terms {et:.2e} dtheta {ed:.2e}")
+    assert et < TOL_TERM
+    assert ed < TOL_DTHETA
+    # cotangent scaling: backward is linear in cot
+    cot2 = torch.tensor([0.5, 2.0, 3.0, 0.25], device="cuda")
+    t2, g2, _ = O.loss_and_grad(mode, P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64),
+                                [w[i] * float(cot2[i]) for i in range(4)], 100.0)
+    dth2 = hip.loss_backward(cfg, m, th, xd, nd, sd, n, w, 100.0, cot2, None, ws)
+    assert rel(dth2.cpu().numpy(), flat(g2)) < TOL_DTHETA
+
+
+@pytest.mark.parametrize("hidden,n,seed", NETS)
+def test_loss_s2(hip, hidden, n, seed):
+    P, theta, x, nrm, sdf = setup(hidden, n, seed)
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda")
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    stats = hip.s2_forward_stats(cfg, th, xd, sd, ws)
+    terms = hip.s2_terms(stats, W_S2)
+    t_ref, g_ref, _ = O.loss_and_grad("s2", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), W_S2, 100.0)
+    t_ref = np.array([float(v) for v in t_ref.values()])
+    cot = torch.ones(4, device="cuda")
+    dth = hip.loss_backward(cfg, hip.LOSS_S2, th, xd, nd, sd, n, W_S2, 100.0, cot, stats, ws)
+    et, ed = rel(terms.cpu().numpy(), t_ref), rel(dth.cpu().numpy(), flat(g_ref))
+    print(f"s2 {hidden[0]}x{len(hidden)} n={n}: terms {et:.2e} dtheta {ed:.2e}")
+    assert et < 2e-5 and ed < TOL_DTHETA
+
+
+def test_against_committed_reference_fixture(hip, golden_dir):
+    """HIP vs the reference's own fp32 outputs (golden fixture), not just vs the oracle."""
+    G = np.load(os.path.join(golden_dir, "g2_8x256.npz"))
+    hidden = list(G["hidden"]); n = int(G["n_points"])
+    P, theta, x, nrm, sdf = setup(hidden, n, int(G["param_seed"]))
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda")
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    f, g = hip.query(cfg, th, xd)
+    assert rel(f.cpu().numpy(), G["f64_y"]) < TOL_F
+    assert rel(g.cpu().numpy(), G["f64_g"]) < TOL_G
+    terms = hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, ws)
+    assert rel(terms.cpu().numpy(), G["f64_s1eik_terms"]) < TOL_TERM
+    dth = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.ones(4, device="cuda"), None, ws)
+    d = dth.cpu().numpy()
+    assert rel(d[G["sample"]], G["f64_s1eik_dtheta_sample"]) < TOL_DTHETA
+    assert abs(np.linalg.norm(d.astype(np.float64)) - G["f64_s1eik_dtheta_norm"][0]) / G["f64_s1eik_dtheta_norm"][0] < 1e-5
+
+
+def test_adam_step_matches_torch_semantics(hip):
+    rng = np.random.default_rng(0)
+    n = 10007
+    theta = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32) * 1e-2
+    th = dev(theta.copy()); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    ref = theta.astype(np.float64).copy(); mr = np.zeros(n); vr = np.zeros(n)
+    for t in range(1, 6):
+        gg = g * t
+        hip.adam_step(th, dev(gg), m, v, t, 1e-3)
+        O.adam_step(ref, gg.astype(np.float64), mr, vr, t, 1e-3)
+    assert rel(th.cpu().numpy(), ref) < 1e-6
+
+
+def test_unsupported_configs_fail_loudly(hip):
+    from diffudf_amd import _lib
+    cfg = hip.make_cfg([64] * 2)
+    ws = hip.workspace_for(cfg, 128, "cuda")
+    z = torch.zeros(128, 3, device="cuda")
+    th = torch.zeros(hip.theta_count(cfg), device="cuda")
+    with pytest.raises(_lib.DudfError):
+        hip.loss_forward(cfg, hip.LOSS_S1, th, z, z, z[:, 0].contiguous(), 128, [1e4, 1e4, 1e4, 1e3], 100.0, ws)
+    with pytest.raises(_lib.DudfError):
+        hip.make_cfg([64, 32])
+    with pytest.raises(_lib.DudfError):
+        hip.query(hip.make_cfg([48, 48]), th, z)
