@@ -14,7 +14,7 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, const float*
     SweepArgs a;
     a.theta = theta; a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt;
     a.x = x; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
-    a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R; a.A = ws + lo.ws_A;
+    a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R; a.E = ws + lo.ws_E; a.A = ws + lo.ws_A;
     a.Z = ws + lo.ws_Z;
     a.n = lo.n; a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.off_wo = lo.off_wo; a.off_bo = lo.off_bo;
@@ -141,8 +141,8 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t
     if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
     if (layer < 0 || layer >= lo.L) return DUDF_E_BADCFG;
     float* ws = reinterpret_cast<float*>(workspace);
-    const int64_t offs[6] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_R, lo.ws_A, lo.ws_Z};
-    if (which < 0 || which > 5) return DUDF_E_BADMODE;
+    const int64_t offs[7] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R};
+    if (which < 0 || which > 6) return DUDF_E_BADMODE;
     return dudf_launch_read_stash(lo, ws + offs[which], layer, out, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -20,7 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   w1t16  [16][H]     rows 0..2 = W_1^T, rest 0: A-operand of the last reverse step (df/dx)
 //   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps
 //   y [np], g [np][4], ybar [np], gbar [np][4]
-//   six stash arrays, each [L][H/4][np][4]:  element (layer li, feature f, point p) lives at
+//   seven stash arrays (s, c, q, r, e, A, zbar), each [L][H/4][np][4]:  element (layer li, feature f, point p) lives at
 //       ((li*(H/4) + f/4)*np + p)*4 + f%4
 //   i.e. "feature-quad major, point minor": the 16x16x4 MFMA accumulator of a wave (feature rows
 //   4q..4q+3 of a tile in its 4 registers, point = lane&15) is one aligned 16-byte store per lane,
@@ -34,7 +34,7 @@ struct DudfLayout {
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
     int64_t ws_w1b, ws_w1t16, ws_wt, ws_y, ws_g, ws_ybar, ws_gbar;
-    int64_t ws_S, ws_C, ws_Q, ws_R, ws_A, ws_Z, ws_acc;
+    int64_t ws_S, ws_C, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array
     size_t total_bytes;
 };
@@ -61,7 +61,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, DudfLayou
     lo->stash_layer = (int64_t)H * lo->np;
     const int64_t stash = (int64_t)L * lo->stash_layer;
     lo->ws_S = take(stash); lo->ws_C = take(stash); lo->ws_Q = take(stash);
-    lo->ws_R = take(stash); lo->ws_A = take(stash); lo->ws_Z = take(stash);
+    lo->ws_R = take(stash); lo->ws_E = take(stash); lo->ws_A = take(stash); lo->ws_Z = take(stash);
     lo->ws_acc = take(2 * DUDF_NACC);
     lo->total_bytes = (size_t)o * sizeof(float);
     return 0;
@@ -73,7 +73,7 @@ struct SweepArgs {
     const float* x;           // (n,3)
     float* y; float* g;       // [np], [np][4]
     const float* ybar; const float* gbar;
-    float *S, *C, *Q, *R, *A, *Z;
+    float *S, *C, *Q, *R, *E, *A, *Z;
     int64_t n, np, stash_layer;
     int64_t off_hid, hid_stride, off_wo, off_bo;
     int L; float w0;

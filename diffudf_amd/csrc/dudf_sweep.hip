@@ -97,7 +97,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
         *DUDF_AT(a.A, ub, vo) = out;
-        *DUDF_AT(a.R, ub, vo) = o2 * acc;                       // e_l = r_l Q_l
+        *DUDF_AT(a.E, ub, vo) = o2 * acc;                       // e_l = r_l Q_l
     } else {                                         // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
         *DUDF_AT(a.Z, ub, vo) = out;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, u
         o2 = *DUDF_CAT(a.R, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
         o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = a.have_e ? *DUDF_CAT(a.R, ub, vo) : f32x4{0, 0, 0, 0};   // no df/dx terms (loss_s2): e_l == 0
+        o2 = a.have_e ? *DUDF_CAT(a.E, ub, vo) : f32x4{0, 0, 0, 0};   // no df/dx terms (loss_s2): e_l == 0
     } else {
         o1 = f32x4{0, 0, 0, 0}; o2 = o1;
     }

@@ -139,7 +139,7 @@ def adam_step(theta, dtheta, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.9
 def read_stash(cfg, which, layer, n, ws):
     """Diagnostic: (n,H) copy of one stashed quantity ('s','c','q','e','A','zbar') of hidden layer `layer`."""
     lib = _lib.load()
-    idx = {"s": 0, "c": 1, "q": 2, "e": 3, "r": 3, "A": 4, "zbar": 5}[which]
+    idx = {"s": 0, "c": 1, "q": 2, "e": 3, "A": 4, "zbar": 5, "r": 6}[which]
     out = torch.empty(n, cfg.hidden, dtype=torch.float32, device=ws.buf.device)
     rc = lib.dudf_debug_read_stash(ctypes.byref(cfg), idx, layer, n, _ptr(out), _ptr(ws.buf), ws.nbytes, _stream())
     _lib.check(rc, "dudf_debug_read_stash")

@@ -95,7 +95,7 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
                    void* stream);
 
 /* Test/diagnostic hook: copy one stashed per-layer quantity of the last sweep into out (n,H) row-major.
- * which: 0 s_l, 1 c_l, 2 q_l, 3 e_l (r_l before backward), 4 A_l, 5 zbar_l; layer: 0-based hidden layer. */
+ * which: 0 s_l, 1 c_l, 2 q_l, 3 e_l, 4 A_l, 5 zbar_l, 6 r_l; layer: 0-based hidden layer. */
 int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t n,
                           float* out, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -36,7 +36,7 @@ def test_host_only_calls():
     assert lib.dudf_theta_count(ctypes.byref(cfg)) == 461825
     nb = lib.dudf_workspace_bytes(ctypes.byref(cfg), 29970)
     np_ = (29970 + 127) // 128 * 128
-    assert nb >= 6 * 8 * 256 * np_ * 4
+    assert nb >= 7 * 8 * 256 * np_ * 4
     bad = _lib.NetCfg(3, 8, 100, 30.0)
     assert lib.dudf_theta_count(ctypes.byref(bad)) == -1
     assert lib.dudf_workspace_bytes(ctypes.byref(bad), 10) == 0
