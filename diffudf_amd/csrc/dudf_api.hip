@@ -1,6 +1,35 @@
 // C-ABI glue: argument checks, workspace layout, kernel sequencing.  See include/dudf_hip.h.
 #include "dudf_internal.h"
+#include <stdio.h>
 #include <string.h>
+#include <vector>
+
+// ---- per-kernel HIP-event timing ---------------------------------------------------------------------------
+namespace {
+struct ProfRec { int slot; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t g_prof_open[PROF_NSLOTS];
+const char* kProfNames[PROF_NSLOTS] = {"pack", "sweep_fwd", "sweep_rev", "sweep_adj_fwd", "sweep_adj_rev",
+                                       "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam", "other"};
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+
+void dudf_prof_begin(int slot, hipStream_t st) {
+    if (!g_prof_on) return;
+    g_prof_open[slot] = prof_event();
+    (void)hipEventRecord(g_prof_open[slot], st);
+}
+void dudf_prof_end(int slot, hipStream_t st) {
+    if (!g_prof_on) return;
+    hipEvent_t e1 = prof_event();
+    (void)hipEventRecord(e1, st);
+    g_prof_recs.push_back({slot, g_prof_open[slot], e1});
+}
 
 namespace {
 
@@ -131,6 +160,33 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
     if (n <= 0 || step < 1) return DUDF_E_BADCFG;
     return dudf_launch_adam(theta, dtheta, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale,
                             reinterpret_cast<hipStream_t>(stream));
+}
+
+int dudf_profile_enable(int on) {
+    g_prof_on = (on != 0);
+    return 0;
+}
+
+int dudf_profile_dump(char* buf, size_t buflen) {
+    double tot[PROF_NSLOTS] = {0};
+    long cnt[PROF_NSLOTS] = {0};
+    for (auto& r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            tot[r.slot] += ms; cnt[r.slot] += 1;
+        }
+        g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1);
+    }
+    g_prof_recs.clear();
+    size_t off = 0;
+    for (int i = 0; i < PROF_NSLOTS; ++i) {
+        if (!cnt[i]) continue;
+        int w = snprintf(buf + off, off < buflen ? buflen - off : 0, "%s %ld %.6f\n", kProfNames[i], cnt[i], tot[i]);
+        if (w < 0 || off + (size_t)w >= buflen) return DUDF_E_WORKSPACE;
+        off += (size_t)w;
+    }
+    if (off < buflen) buf[off] = 0;
+    return 0;
 }
 
 int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t n, float* out, void* workspace,

@@ -97,3 +97,14 @@ int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n
                      double eps, int64_t step, double gscale, hipStream_t st);
 int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, float* out, hipStream_t st);
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, hipStream_t st);
+
+// ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
+enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,
+       PROF_WGRAD_SMALL, PROF_LOSS_FWD, PROF_LOSS_BWD, PROF_ADAM, PROF_OTHER, PROF_NSLOTS };
+void dudf_prof_begin(int slot, hipStream_t st);
+void dudf_prof_end(int slot, hipStream_t st);
+struct DudfProfScope {
+    int slot; hipStream_t st;
+    DudfProfScope(int s, hipStream_t t) : slot(s), st(t) { dudf_prof_begin(slot, st); }
+    ~DudfProfScope() { dudf_prof_end(slot, st); }
+};

@@ -247,6 +247,7 @@ LossArgs make_loss_args(const DudfLayout& lo, const float* normals, const float*
 }  // namespace
 
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
+    DudfProfScope prof(PROF_PACK, st);
     int64_t n = (int64_t)(lo.L - 1) * lo.H * lo.H;
     if (n < 16 * (int64_t)lo.H) n = 16 * (int64_t)lo.H;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, ws + lo.ws_w1b,
@@ -256,6 +257,7 @@ int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStr
 
 int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, float* ws, float* out_terms, hipStream_t st) {
+    DudfProfScope prof(PROF_LOSS_FWD, st);
     LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
     hipError_t e = hipMemsetAsync(a.acc, 0, 4 * sizeof(double), st);
     if (e != hipSuccess) return (int)e;
@@ -271,6 +273,7 @@ int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, c
 int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, const float* cot, const double* stats, float* ws,
                          hipStream_t st) {
+    DudfProfScope prof(PROF_LOSS_BWD, st);
     LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
     a.cot = cot; a.stats = stats;
     const int grid = grid_for(lo.np);
@@ -295,6 +298,7 @@ int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms,
 
 int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
                      double eps, int64_t step, double gscale, hipStream_t st) {
+    DudfProfScope prof(PROF_ADAM, st);
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, theta, g, m, v, n, (float)b1, (float)b2,
                        (float)eps, (float)(lr / bc1), (float)sqrt(bc2), (float)gscale);

@@ -281,6 +281,7 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
 }  // namespace
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st) {
+    DudfProfScope prof(PROF_SWEEP_FWD + which, st);
     switch (H) {
         case 32: return launch_h<32>(which, a, st);
         case 64: return launch_h<64>(which, a, st);

@@ -272,6 +272,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dt
     a.have_g = have_g;
     int rc = 0;
     {
+        DudfProfScope prof(PROF_WGRAD_HIDDEN, st);
         switch (lo.H) {
             case 32: rc = launch_hidden<32>(a, st); break;
             case 64: rc = launch_hidden<64>(a, st); break;
@@ -287,6 +288,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dt
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
     s.pts_per_block = 512;
     const int grid = (int)((lo.np + s.pts_per_block - 1) / s.pts_per_block);
+    DudfProfScope prof(PROF_WGRAD_SMALL, st);
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid), dim3(256), 0, st, s);
     return (int)hipGetLastError();
 }

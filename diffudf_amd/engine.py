@@ -1,0 +1,75 @@
+# coding: utf-8
+"""One training step of the reference loop (reference train.py:195-222) on flat device buffers:
+
+    zero_grad -> loss dict -> sum -> backward -> [all-reduce] -> Adam
+
+driven through the C ABI.  This is what `bench.py` times and what `train.py` runs; the
+autograd-facing wrappers in `loss_functions.py` give the same numbers term by term.
+
+Multi-GPU (one process per GPU, torch.distributed 'nccl' == RCCL over xGMI): the point batch is
+sharded, every rank computes its share  sum_local(.)/n_global  of each term and of d(loss)/d(theta),
+and ONE all-reduce(sum) of the flat [dtheta | 4 terms] buffer makes them global.  loss_s2 needs one
+extra 3-double all-reduce of (count, sum, sum of squares) between its forward and backward
+(SURVEY.md §8(e)).  Parameters stay replicated: every rank applies the identical Adam update.
+"""
+import torch
+
+from . import hip_ops
+
+
+class TrainEngine:
+    def __init__(self, hidden, theta, w0=30.0, process_group=None, betas=(0.9, 0.999), eps=1e-8):
+        self.cfg = hip_ops.make_cfg(hidden, w0)
+        n_theta = hip_ops.theta_count(self.cfg)
+        if theta.numel() != n_theta or theta.dtype != torch.float32 or theta.device.type != "cuda":
+            raise ValueError(f"theta must be a flat fp32 CUDA tensor of {n_theta} elements")
+        self.theta = theta
+        self.device = theta.device
+        # [dtheta | terms(4)] in one buffer so that one collective moves both
+        self.flat = torch.zeros(n_theta + 4, dtype=torch.float32, device=self.device)
+        self.dtheta = self.flat[:n_theta]
+        self.terms = self.flat[n_theta:]
+        self.exp_avg = torch.zeros(n_theta, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n_theta, dtype=torch.float32, device=self.device)
+        self.betas, self.eps = betas, eps
+        self.t = 0
+        self.ones = torch.ones(4, dtype=torch.float32, device=self.device)
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def loss_and_grad(self, mode, x, normals, sdf, weights, alpha=100.0, n_global=None):
+        """Fills self.terms (global loss terms) and self.dtheta (global gradient)."""
+        n = x.shape[0]
+        n_global = n * self.world if n_global is None else n_global
+        ws = hip_ops.workspace_for(self.cfg, n, self.device)
+        if mode == hip_ops.LOSS_S2:
+            stats = hip_ops.s2_forward_stats(self.cfg, self.theta, x, sdf, ws)
+            self._allreduce(stats)
+            self.terms.zero_()
+            self.terms[:2] = hip_ops.s2_terms(stats, weights)
+            hip_ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
+                                  stats, ws, dtheta=self.dtheta)
+            self._allreduce(self.dtheta)
+        else:
+            terms = hip_ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws)
+            hip_ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
+                                  None, ws, dtheta=self.dtheta)
+            self.terms.copy_(terms)
+            self._allreduce(self.flat)
+        return self.terms
+
+    def adam(self, lr):
+        self.t += 1
+        hip_ops.adam_step(self.theta, self.dtheta, self.exp_avg, self.exp_avg_sq, self.t, lr, self.betas[0],
+                          self.betas[1], self.eps)
+
+    def step(self, mode, x, normals, sdf, weights, alpha=100.0, lr=1e-4, n_global=None):
+        terms = self.loss_and_grad(mode, x, normals, sdf, weights, alpha, n_global)
+        self.adam(lr)
+        return terms

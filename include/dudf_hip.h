@@ -99,6 +99,12 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
 int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t n,
                           float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement hook (bench.py): while enabled, every kernel the library launches is bracketed by HIP
+ * events ON THE STREAM IT IS LAUNCHED ON.  dudf_profile_dump synchronises those events and writes one
+ * text line per kernel kind, "<name> <launches> <total_ms>\n", into buf (host), then clears the log. */
+int dudf_profile_enable(int on);
+int dudf_profile_dump(char* buf, size_t buflen);
+
 /* library / build identification, host string */
 const char* dudf_version(void);
 
