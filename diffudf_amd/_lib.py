@@ -46,6 +46,9 @@ SYMBOLS = {
     "dudf_s2_terms": (ctypes.c_int, [_P, _DBL, _P, _P]),
     "dudf_loss_backward": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64,
                                           _DBL, ctypes.c_double, _P, _P, _P, ctypes.c_int, _P, ctypes.c_size_t, _P]),
+    "dudf_fields_forward": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_fields_backward": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int, _P,
+                                            ctypes.c_size_t, _P]),
     "dudf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_double, _P]),
     "dudf_profile_enable": (ctypes.c_int, [ctypes.c_int]),

@@ -155,6 +155,48 @@ int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta, co
     return dudf_launch_wgrad(lo, x, ws, dtheta, have_g, st);
 }
 
+int dudf_fields_forward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f,
+                        float* out_g, void* workspace, size_t workspace_bytes, void* stream) {
+    DudfLayout lo;
+    int rc = dudf_make_layout(cfg, n, &lo);
+    if (rc) return rc;
+    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(workspace);
+    if ((rc = dudf_launch_pack(lo, theta, ws, st))) return rc;
+    SweepArgs a = make_sweep_args(lo, theta, x, ws);
+    a.store_s = 1; a.store_c = 1; a.train = 1;
+    if ((rc = dudf_launch_sweep(SWEEP_FWD, lo.H, a, st))) return rc;
+    if ((rc = dudf_launch_sweep(SWEEP_REV, lo.H, a, st))) return rc;
+    return dudf_launch_copy_out(lo, ws, out_f, out_g, st);
+}
+
+int dudf_fields_backward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, const float* ybar,
+                         const float* gbar, float* dtheta, int accumulate, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    DudfLayout lo;
+    int rc = dudf_make_layout(cfg, n, &lo);
+    if (rc) return rc;
+    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(workspace);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)lo.n_theta * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if ((rc = dudf_launch_copy_in(lo, ybar, gbar, ws, st))) return rc;
+    SweepArgs a = make_sweep_args(lo, theta, x, ws);
+    a.train = 1;
+    const int have_g = gbar != nullptr;
+    if (have_g) {
+        if ((rc = dudf_launch_sweep(SWEEP_ADJ_FWD, lo.H, a, st))) return rc;
+    } else {
+        a.have_e = 0;
+    }
+    if ((rc = dudf_launch_sweep(SWEEP_ADJ_REV, lo.H, a, st))) return rc;
+    return dudf_launch_wgrad(lo, x, ws, dtheta, have_g, st);
+}
+
 int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                    double beta1, double beta2, double eps, int64_t step, double grad_scale, void* stream) {
     if (n <= 0 || step < 1) return DUDF_E_BADCFG;

@@ -96,6 +96,7 @@ int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms,
 int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
                      double eps, int64_t step, double gscale, hipStream_t st);
 int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, float* out, hipStream_t st);
+int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st);
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, hipStream_t st);
 
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------

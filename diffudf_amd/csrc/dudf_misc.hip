@@ -225,6 +225,18 @@ __global__ __launch_bounds__(256) void copy_out_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void copy_in_kernel(const float* __restrict__ ybar, const float* __restrict__ gbar,
+                                                      float* __restrict__ wy, float* __restrict__ wg, int64_t n,
+                                                      int64_t np) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
+        const bool in = p < n;
+        wy[p] = (in && ybar) ? ybar[p] : 0.f;
+        f32x4 g = {0, 0, 0, 0};
+        if (in && gbar) g = f32x4{gbar[p * 3], gbar[p * 3 + 1], gbar[p * 3 + 2], 0.f};
+        *reinterpret_cast<f32x4*>(wg + p * 4) = g;
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -314,5 +326,12 @@ int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, fl
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, hipStream_t st) {
     hipLaunchKernelGGL(copy_out_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, ws + lo.ws_g, out_f,
                        out_g, lo.n);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(copy_in_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, ybar, gbar, ws + lo.ws_ybar,
+                       ws + lo.ws_gbar, lo.n, lo.np);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,93 @@
+# coding: utf-8
+"""Input derivatives of the SIREN field (reference src/diff_operators.py:187-227), from the HIP sweeps
+instead of repeated `torch.autograd.grad`.
+
+`gradient(y, x)` keeps the reference call shape: `y`/`x` are the "model_out"/"model_in" entries of
+`SIREN.forward(...)`.  The result is the analytic reverse sweep  a_{l-1} = W_l^T (w0 cos(w0 z_l) * a_l)
+evaluated by the kernel (SWEEP_REV); it is a plain tensor — training through df/dx goes through the fused
+losses in `loss_functions.py` (or `fields()` below for hand-written losses), which carry their own backward.
+"""
+import torch
+
+from . import hip_ops
+from ._lib import DudfError
+
+
+def _source(y, x):
+    src = getattr(y, "_dudf_src", None)
+    if src is None:
+        raise DudfError("gradient/hessian: `y` was not produced by diffudf_amd.model.SIREN.forward "
+                        "(generic autograd graphs have no HIP path here)")
+    model, coords = src[0](), src[1]
+    if model is None:
+        raise DudfError("the SIREN that produced `y` no longer exists")
+    if x is not coords:
+        raise DudfError("gradient(y, x): `x` must be the 'model_in' tensor returned together with `y`")
+    return model, coords
+
+
+def gradient(y, x, grad_outputs=None):
+    """dy/dx, shaped like x — reference src/diff_operators.py:208-212."""
+    model, coords = _source(y, x)
+    x2 = coords.detach().reshape(-1, 3)
+    _, g = hip_ops.query(model.hip_cfg, model.flat_parameters(), x2, want_grad=True)
+    g = g.reshape(coords.shape)
+    if grad_outputs is not None:
+        g = g * grad_outputs.reshape(coords.shape[:-1] + (1,))
+    return g
+
+
+def hessian(y, x):
+    """reference src/diff_operators.py:187-193.  The forward-over-reverse HIP sweep is the next
+    kernel on the list; until it exists this raises instead of silently running PyTorch autograd."""
+    _source(y, x)
+    raise DudfError("hessian(y, x): the HIP Hessian sweep is not built yet; no CPU/autograd fallback by design")
+
+
+def divergence(y, x):
+    raise DudfError("divergence: needs the HIP Hessian sweep (not built yet)")
+
+
+def laplace(y, x):
+    raise DudfError("laplace: needs the HIP Hessian sweep (not built yet)")
+
+
+def jacobian(y, x):
+    raise DudfError("jacobian of a derived vector field: third-order path (SURVEY.md §7), not built yet")
+
+
+class _Fields(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        x2 = x.detach().reshape(-1, 3).contiguous().float()
+        theta = model.flat_parameters()
+        ws = hip_ops.workspace_for(model.hip_cfg, x2.shape[0], x2.device)
+        f, g = hip_ops.fields_forward(model.hip_cfg, theta, x2, ws)
+        ctx.model, ctx.ws, ctx.x2 = model, ws, x2
+        ctx.stamp = _stamp(ws)
+        return f, g
+
+    @staticmethod
+    def backward(ctx, fbar, gbar):
+        model, ws, x2 = ctx.model, ctx.ws, ctx.x2
+        if _stamp(ws, peek=True) != ctx.stamp:
+            raise DudfError("fields(): the workspace was reused by another forward before backward()")
+        theta = model.flat_parameters()
+        fb = None if fbar is None else fbar.contiguous().float()
+        gb = None if gbar is None else gbar.contiguous().float()
+        if fb is None:
+            fb = torch.zeros(x2.shape[0], device=x2.device)
+        dtheta = hip_ops.fields_backward(model.hip_cfg, theta, x2, fb, gb, ws)
+        return (None, None) + tuple(model.split_flat(dtheta))
+
+
+def _stamp(ws, peek=False):
+    if not peek:
+        ws.generation = getattr(ws, "generation", 0) + 1
+    return getattr(ws, "generation", 0)
+
+
+def fields(model, x):
+    """(f (n,), df/dx (n,3)) for points x (..., 3), differentiable with respect to the model parameters:
+    lets a loss written in plain PyTorch on top of the two fields train through the HIP adjoint sweeps."""
+    return _Fields.apply(model, x, *model.parameters())

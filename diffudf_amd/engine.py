@@ -14,15 +14,22 @@ extra 3-double all-reduce of (count, sum, sum of squares) between its forward an
 """
 import torch
 
-from . import hip_ops
+from . import hip_ops as _hip_ops
+
+LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
 
 
 class TrainEngine:
-    def __init__(self, hidden, theta, w0=30.0, process_group=None, betas=(0.9, 0.999), eps=1e-8):
-        self.cfg = hip_ops.make_cfg(hidden, w0)
-        n_theta = hip_ops.theta_count(self.cfg)
-        if theta.numel() != n_theta or theta.dtype != torch.float32 or theta.device.type != "cuda":
-            raise ValueError(f"theta must be a flat fp32 CUDA tensor of {n_theta} elements")
+    def __init__(self, hidden, theta, w0=30.0, process_group=None, betas=(0.9, 0.999), eps=1e-8, ops=None):
+        """`ops` defaults to the HIP kernels.  It is a parameter only so that the CPU/gloo tests can drive the
+        distributed bookkeeping below with a stand-in compute backend; nothing in the product passes it."""
+        self.ops = _hip_ops if ops is None else ops
+        self.cfg = self.ops.make_cfg(hidden, w0)
+        n_theta = self.ops.theta_count(self.cfg)
+        if theta.numel() != n_theta or theta.dtype != torch.float32:
+            raise ValueError(f"theta must be a flat fp32 tensor of {n_theta} elements")
+        if ops is None and theta.device.type != "cuda":
+            raise ValueError("theta must live on the GPU: the HIP path has no CPU fallback")
         self.theta = theta
         self.device = theta.device
         # [dtheta | terms(4)] in one buffer so that one collective moves both
@@ -44,30 +51,31 @@ class TrainEngine:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def loss_and_grad(self, mode, x, normals, sdf, weights, alpha=100.0, n_global=None):
-        """Fills self.terms (global loss terms) and self.dtheta (global gradient)."""
+        """Fills self.terms (global loss terms) and self.dtheta (global gradient); returns self.terms."""
+        ops = self.ops
         n = x.shape[0]
         n_global = n * self.world if n_global is None else n_global
-        ws = hip_ops.workspace_for(self.cfg, n, self.device)
-        if mode == hip_ops.LOSS_S2:
-            stats = hip_ops.s2_forward_stats(self.cfg, self.theta, x, sdf, ws)
-            self._allreduce(stats)
+        ws = ops.workspace_for(self.cfg, n, self.device)
+        if mode == LOSS_S2:
+            stats = ops.s2_forward_stats(self.cfg, self.theta, x, sdf, ws)
+            self._allreduce(stats)                       # (count, sum, sum sq) of the on-surface predictions
             self.terms.zero_()
-            self.terms[:2] = hip_ops.s2_terms(stats, weights)
-            hip_ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
-                                  stats, ws, dtheta=self.dtheta)
+            self.terms[:2] = ops.s2_terms(stats, weights)
+            ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
+                              stats, ws, dtheta=self.dtheta)
             self._allreduce(self.dtheta)
         else:
-            terms = hip_ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws)
-            hip_ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
-                                  None, ws, dtheta=self.dtheta)
+            terms = ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws)
+            ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
+                              None, ws, dtheta=self.dtheta)
             self.terms.copy_(terms)
-            self._allreduce(self.flat)
+            self._allreduce(self.flat)                   # one collective: gradient + the four loss scalars
         return self.terms
 
     def adam(self, lr):
         self.t += 1
-        hip_ops.adam_step(self.theta, self.dtheta, self.exp_avg, self.exp_avg_sq, self.t, lr, self.betas[0],
-                          self.betas[1], self.eps)
+        self.ops.adam_step(self.theta, self.dtheta, self.exp_avg, self.exp_avg_sq, self.t, lr, self.betas[0],
+                           self.betas[1], self.eps)
 
     def step(self, mode, x, normals, sdf, weights, alpha=100.0, lr=1e-4, n_global=None):
         terms = self.loss_and_grad(mode, x, normals, sdf, weights, alpha, n_global)

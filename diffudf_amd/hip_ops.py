@@ -129,6 +129,29 @@ def loss_backward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, c
     return dtheta
 
 
+def fields_forward(cfg, theta, x, ws):
+    """(f (n,), df/dx (n,3)) with the training stash kept in ws (for fields_backward)."""
+    lib = _lib.load()
+    n = x.shape[0]
+    f = torch.empty(n, dtype=torch.float32, device=x.device)
+    g = torch.empty(n, 3, dtype=torch.float32, device=x.device)
+    rc = lib.dudf_fields_forward(ctypes.byref(cfg), _ptr(theta), _ptr(x), n, _ptr(f), _ptr(g), _ptr(ws.buf),
+                                 ws.nbytes, _stream())
+    _lib.check(rc, "dudf_fields_forward")
+    return f, g
+
+
+def fields_backward(cfg, theta, x, ybar, gbar, ws, dtheta=None, accumulate=False):
+    lib = _lib.load()
+    if dtheta is None:
+        dtheta = torch.empty_like(theta)
+        accumulate = False
+    rc = lib.dudf_fields_backward(ctypes.byref(cfg), _ptr(theta), _ptr(x), x.shape[0], _ptr(ybar), _ptr(gbar),
+                                  _ptr(dtheta), 1 if accumulate else 0, _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_fields_backward")
+    return dtheta
+
+
 def adam_step(theta, dtheta, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     lib = _lib.load()
     rc = lib.dudf_adam_step(_ptr(theta), _ptr(dtheta), _ptr(exp_avg), _ptr(exp_avg_sq), theta.numel(), float(lr),

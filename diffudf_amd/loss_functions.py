@@ -1,0 +1,98 @@
+# coding: utf-8
+"""`loss_s1`, `loss_s2`, `loss_siren` with the reference signatures and return contract
+(reference src/loss_functions.py:123-155, :106-121, :82-104):
+
+    loss = loss_s1(model, model_input, {'normals': n, 'sdf': u}, loss_weights, alpha)
+    -> dict[str, 0-dim tensor]  (already weight-scaled; keys and order as the reference's losses.csv)
+    train_loss = sum(loss.values()); train_loss.backward()  -> p.grad for every model parameter
+
+Each call is ONE forward of the fused HIP path (SIREN sweep, df/dx sweep, per-point loss + reduction);
+`.backward()` runs the two adjoint sweeps and the weight-gradient GEMM with the actual upstream gradient of
+every term.  The activations stay in the per-network workspace in between, so — like the reference's graph —
+a loss dict must be backpropagated before the next loss call on the same network.
+
+Hessian term of loss_s1 (loss_weights[2] != 0, reference :140-145): needs the Hessian sweep + closed-form
+eigh backward, which is not built yet -> raises (there is deliberately no autograd fallback).
+"""
+import torch
+
+from . import hip_ops
+from ._lib import DudfError
+
+_S1_KEYS = ("sdf_on_surf", "sdf_off_surf", "hessian_constraint", "grad_constraint")
+_SIREN_KEYS = ("sdf_on_surf", "sdf_off_surf", "normal_constraint", "grad_constraint")
+_S2_KEYS = ("sdf_on_surf", "std_on_surf")
+
+
+def _prep(model_input, gt):
+    x = model_input.detach().reshape(-1, 3).contiguous().float()
+    sdf = gt['sdf'].detach().reshape(-1).contiguous().float()
+    normals = gt['normals'].detach().reshape(-1, 3).contiguous().float()
+    if x.device.type != "cuda":
+        raise DudfError("loss_*: tensors must be on the GPU; there is no CPU fallback path")
+    if sdf.shape[0] != x.shape[0] or normals.shape[0] != x.shape[0]:
+        raise ValueError("model_input, gt['normals'] and gt['sdf'] must describe the same points")
+    return x, normals, sdf
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, mode, x, normals, sdf, weights, alpha, n_global, *params):
+        cfg = model.hip_cfg
+        theta = model.flat_parameters()
+        ws = hip_ops.workspace_for(cfg, x.shape[0], x.device)
+        ws.generation = getattr(ws, "generation", 0) + 1
+        stats = None
+        if mode == hip_ops.LOSS_S2:
+            stats = hip_ops.s2_forward_stats(cfg, theta, x, sdf, ws)
+            reducer = getattr(model, "dudf_allreduce", None)
+            if reducer is not None:
+                reducer(stats)
+            terms = hip_ops.s2_terms(stats, weights)
+        else:
+            terms = hip_ops.loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws)
+        ctx.model, ctx.mode, ctx.ws, ctx.stats = model, mode, ws, stats
+        ctx.args = (x, normals, sdf, list(weights), alpha, n_global)
+        ctx.stamp = ws.generation
+        return terms
+
+    @staticmethod
+    def backward(ctx, grad_terms):
+        model, mode, ws = ctx.model, ctx.mode, ctx.ws
+        if ws.generation != ctx.stamp:
+            raise DudfError("loss backward(): another loss/forward ran on this network before backward(); "
+                            "backpropagate each loss dict before computing the next one")
+        x, normals, sdf, weights, alpha, n_global = ctx.args
+        cot = torch.zeros(4, dtype=torch.float32, device=x.device)
+        cot[:grad_terms.numel()] = grad_terms.float()
+        theta = model.flat_parameters()
+        dtheta = hip_ops.loss_backward(model.hip_cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot,
+                                       ctx.stats, ws)
+        return (None,) * 8 + tuple(model.split_flat(dtheta))
+
+
+def _run(model, mode, model_input, gt, loss_weights, alpha, keys):
+    x, normals, sdf = _prep(model_input, gt)
+    n_global = int(getattr(model, "dudf_n_global", 0) or x.shape[0])
+    terms = _FusedLoss.apply(model, mode, x, normals, sdf, tuple(float(w) for w in loss_weights), float(alpha),
+                             n_global, *model.parameters())
+    return {k: terms[i] for i, k in enumerate(keys)}
+
+
+def loss_s1(model, model_input, gt, loss_weights, alpha):
+    """Hyperbolic-scaled UDF loss, stage 1 — reference src/loss_functions.py:123-155."""
+    if loss_weights[2] != 0:
+        raise DudfError("loss_s1 with a non-zero hessian_constraint weight needs the HIP Hessian + eigh-backward "
+                        "kernels, which are not built yet (no autograd fallback by design); use "
+                        "loss_weights[2] = 0 for the Eikonal-only loss")
+    return _run(model, hip_ops.LOSS_S1, model_input, gt, loss_weights, alpha, _S1_KEYS)
+
+
+def loss_s2(model, model_input, gt, loss_weights, alpha):
+    """Stage 2: |mean| and unbiased std of the on-surface predictions — reference :106-121."""
+    return _run(model, hip_ops.LOSS_S2, model_input, gt, list(loss_weights)[:2], alpha, _S2_KEYS)
+
+
+def loss_siren(model, model_input, gt, loss_weights):
+    """SIREN's SDF loss (`gt_mode='siren'`) — reference :82-104."""
+    return _run(model, hip_ops.LOSS_SIREN, model_input, gt, loss_weights, 0.0, _SIREN_KEYS)

@@ -1,0 +1,174 @@
+# coding: utf-8
+"""`SIREN` with the reference's constructor, state_dict keys and forward contract
+(reference src/model.py:48-135), computing through the HIP kernels.
+
+What is kept from the reference interface
+  * `SIREN(n_in_features, n_out_features, hidden_layer_config=[], w0=30, ww=None,
+           delay_init=False, activation='sine')`
+  * `.net` is an `nn.Sequential` of `nn.Sequential(nn.Linear[, SineLayer])`, so `state_dict()` keys are
+    `net.{i}.0.weight|bias` and every reference checkpoint loads (reference generate_mc.py:21, train.py:327)
+  * initialisation distributions (src/model.py:7-19, :111-113)
+  * `forward(x) -> {"model_in": x.clone().detach().requires_grad_(True), "model_out": y}` (dict order matters:
+    reference src/evaluate.py:26 unpacks `.values()`)
+
+What is different inside
+  * all 18 parameters are views into ONE flat fp32 buffer in state_dict order — the `theta` the C ABI takes;
+    `torch.optim.Adam(model.parameters())` updates it in place exactly as it updates the reference's tensors
+  * `forward` runs the fused HIP value sweep; there is no PyTorch/CPU fallback: CPU inputs raise.
+"""
+import math
+import weakref
+
+import torch
+from torch import nn
+
+from . import hip_ops
+from ._lib import DudfError
+
+
+class SineLayer(nn.Module):
+    """sin(w0 * x) — reference src/model.py:22-33.  Kept for module structure / repr; the HIP sweep
+    applies it in registers."""
+
+    def __init__(self, w0=30):
+        super().__init__()
+        self.w0 = w0
+
+    def forward(self, x):
+        raise DudfError("SineLayer is evaluated inside the fused HIP sweep; call the SIREN module")
+
+    def __repr__(self):
+        return f"SineLayer(w0={self.w0})"
+
+
+class _SirenValue(torch.autograd.Function):
+    """y = SIREN(x) by the HIP forward sweep.  backward: cotangent on y -> parameters (and to x via df/dx)."""
+
+    @staticmethod
+    def forward(ctx, model, coords, *params):
+        x2 = coords.reshape(-1, 3)
+        theta = model.flat_parameters()
+        f, _ = hip_ops.query(model.hip_cfg, theta, x2, want_grad=False)
+        ctx.model = model
+        ctx.save_for_backward(coords)
+        return f.reshape(coords.shape[:-1] + (1,))
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        model = ctx.model
+        (coords,) = ctx.saved_tensors
+        x2 = coords.reshape(-1, 3).contiguous()
+        theta = model.flat_parameters()
+        ws = hip_ops.workspace_for(model.hip_cfg, x2.shape[0], x2.device)
+        _, g = hip_ops.fields_forward(model.hip_cfg, theta, x2, ws)
+        ybar = grad_y.reshape(-1).contiguous().float()
+        dtheta = hip_ops.fields_backward(model.hip_cfg, theta, x2, ybar, None, ws)
+        gx = (g * ybar[:, None]).reshape(coords.shape) if ctx.needs_input_grad[1] else None
+        return (None, gx) + tuple(model.split_flat(dtheta))
+
+
+class SIREN(nn.Module):
+    def __init__(self, n_in_features, n_out_features, hidden_layer_config=[], w0=30, ww=None, delay_init=False,
+                 activation='sine'):
+        super().__init__()
+        self.w0 = w0
+        self.ww = w0 if ww is None else ww
+        self.activation = activation
+        self.n_in_features, self.n_out_features = n_in_features, n_out_features
+        self.hidden_layer_config = list(hidden_layer_config)
+        dims = [n_in_features] + self.hidden_layer_config + [n_out_features]
+        blocks = []
+        for i in range(len(dims) - 1):
+            mods = [nn.Linear(dims[i], dims[i + 1])]
+            if i < len(dims) - 2:
+                mods.append(SineLayer(self.w0 if i == 0 else self.ww))
+            blocks.append(nn.Sequential(*mods))
+        self.net = nn.Sequential(*blocks)
+        if not delay_init and activation == 'sine':
+            with torch.no_grad():
+                for i, blk in enumerate(self.net):
+                    lin = blk[0]
+                    fan_in = lin.weight.size(-1)
+                    bound = (1.0 / fan_in) if i == 0 else (math.sqrt(6.0 / fan_in) / self.ww)
+                    lin.weight.uniform_(-bound, bound)          # biases keep nn.Linear's default
+        self._flat = None
+        self._flatten()
+
+    # ---- flat parameter storage -------------------------------------------------------------------------
+    def _linears(self):
+        return [blk[0] for blk in self.net]
+
+    def _flatten(self):
+        """(Re)build the flat buffer and point every parameter at its slice of it."""
+        lins = self._linears()
+        with torch.no_grad():
+            flat = torch.cat([torch.cat([l.weight.detach().reshape(-1), l.bias.detach().reshape(-1)]) for l in lins])
+            flat = flat.contiguous().clone()
+            off = 0
+            for l in lins:
+                for p in (l.weight, l.bias):
+                    n = p.numel()
+                    p.data = flat[off:off + n].view(p.shape)
+                    off += n
+        self._flat = flat
+
+    def _is_flat(self):
+        if self._flat is None:
+            return False
+        off = self._flat.data_ptr()
+        es = self._flat.element_size()
+        for l in self._linears():
+            for p in (l.weight, l.bias):
+                if p.data_ptr() != off or p.dtype != self._flat.dtype or p.device != self._flat.device:
+                    return False
+                off += p.numel() * es
+        return True
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if not self._is_flat():
+            self._flatten()
+        return out
+
+    def flat_parameters(self):
+        """theta for the C ABI: flat fp32 CUDA tensor aliasing every parameter (state_dict order)."""
+        if not self._is_flat():
+            self._flatten()
+        return self._flat
+
+    def split_flat(self, flat):
+        """Views of a theta-shaped tensor, one per parameter, in `parameters()` order."""
+        out, off = [], 0
+        for l in self._linears():
+            for p in (l.weight, l.bias):
+                n = p.numel()
+                out.append(flat[off:off + n].view(p.shape))
+                off += n
+        return out
+
+    @property
+    def hip_cfg(self):
+        if self.activation != 'sine':
+            raise DudfError("only activation='sine' has a HIP path (the reference's 'relu' variant is unused by its configs)")
+        if self.ww != self.w0:
+            raise DudfError("HIP path needs ww == w0 (every reference config leaves ww=None)")
+        return hip_ops.make_cfg(self.hidden_layer_config, self.w0, self.n_in_features, self.n_out_features)
+
+    # ---- forward --------------------------------------------------------------------------------------------
+    def forward(self, x):
+        """Same contract as reference src/model.py:116-135."""
+        coords_org = x.clone().detach().requires_grad_(True)
+        if coords_org.device.type != "cuda":
+            raise DudfError("SIREN.forward: inputs must be on the GPU; this build has no CPU/PyTorch fallback path")
+        theta = self.flat_parameters()
+        if theta.dtype != torch.float32:
+            raise DudfError("HIP path is fp32; call model.float()")
+        y = _SirenValue.apply(self, coords_org, *self.parameters())
+        # lets diff_operators.gradient(y, x) find the network that produced y
+        y._dudf_src = (weakref.ref(self), coords_org)
+        return {"model_in": coords_org, "model_out": y}

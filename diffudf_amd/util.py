@@ -1,0 +1,32 @@
+# coding: utf-8
+"""Experiment plumbing with the reference's signatures — reference src/util.py:10-38."""
+import json
+import os
+import shutil
+
+
+def create_output_paths(checkpoint_path, experiment_name, overwrite=True):
+    """<checkpoint_path>/<experiment_name>/{models,reconstructions}; an existing directory is reused when
+    overwrite is False and wiped when it is True."""
+    full_path = os.path.join(checkpoint_path, experiment_name)
+    if os.path.exists(full_path) and overwrite:
+        shutil.rmtree(full_path)
+    for sub in ("models", "reconstructions"):
+        os.makedirs(os.path.join(full_path, sub), exist_ok=True)
+    return full_path
+
+
+def load_experiment_parameters(parameters_path):
+    try:
+        with open(parameters_path, "r") as fin:
+            return json.load(fin)
+    except FileNotFoundError:
+        print("File '{}' not found.".format(parameters_path))
+        return {}
+
+
+def normalize(v):
+    import numpy as np
+    v = np.asarray(v, dtype=float)
+    n = np.linalg.norm(v)
+    return v if n == 0 else v / n

@@ -87,6 +87,17 @@ int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta,
                        const float* cot, const double* stats, float* dtheta, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Generic differentiable fields, for losses written by the caller on top of (f, df/dx) instead of the
+ * reference's three: dudf_fields_forward = dudf_query with the training stash kept in `workspace`;
+ * dudf_fields_backward = d(sum_p ybar[p]*f[p] + gbar[p].df/dx[p]) / d(theta), i.e. what autograd's
+ * backward through `model(x)` and `gradient(y, x)` (reference src/diff_operators.py:208-212 with
+ * create_graph=True) delivers to the parameters.  ybar (n), gbar (n,3) or NULL. */
+int dudf_fields_forward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+                        float* out_f, float* out_g, void* workspace, size_t workspace_bytes, void* stream);
+int dudf_fields_backward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+                         const float* ybar, const float* gbar, float* dtheta, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* torch.optim.Adam.step() with default betas/eps semantics (reference train.py:334-337, :222) on
  * flat buffers.  step = 1-based count after this update.  grad_scale multiplies the gradient
  * first (1/world_size after an all-reduce(sum) is NOT needed here: ranks hold shares of one mean). */

@@ -1,0 +1,195 @@
+# coding: utf-8
+"""GPU: the reference-shaped Python API (SIREN / loss_* / gradient / evaluate / train loop) over the HIP path,
+checked against the oracle and against the reference's own outputs in tests/golden/."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+from diffudf_amd import synth
+from oracle import dudf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+W_S1EIK = [1e4, 1e4, 0.0, 1e3]
+W_S2 = [1e5, 1e5]
+W_SIREN = [3e3, 1e2, 1e2, 5e1]
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def flat(grads):
+    return np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
+
+
+def make_model(hidden, seed):
+    from src.model import SIREN                      # through the reference-named shim on purpose
+    m = SIREN(3, 1, hidden, w0=30)
+    P32 = synth.siren_params(hidden, seed=seed)
+    sd = {}
+    for i, (w, b) in enumerate(P32):
+        sd[f"net.{i}.0.weight"] = torch.from_numpy(w); sd[f"net.{i}.0.bias"] = torch.from_numpy(b)
+    m.load_state_dict(sd)
+    return m.to("cuda:0"), [(w.astype(np.float64), b.astype(np.float64)) for w, b in P32]
+
+
+def batch(n, seed, step=0):
+    x, nrm, sdf = synth.training_batch(n, seed=seed, step=step)
+    t = lambda a: torch.from_numpy(a)[None].to("cuda:0")  # noqa: E731
+    return (x, nrm, sdf), (t(x), t(nrm), t(sdf))
+
+
+@pytest.mark.parametrize("case", ["s1eik", "s2", "siren"])
+def test_loss_dict_and_param_grads(case):
+    from src.loss_functions import loss_s1, loss_s2, loss_siren
+    hidden = [256] * 8
+    model, P = make_model(hidden, 123)
+    (x, nrm, sdf), (xd, nd, sd) = batch(700, 123)
+    gt = {"normals": nd, "sdf": sd}
+    if case == "s1eik":
+        loss = loss_s1(model, xd, gt, W_S1EIK, 100); mode, w = "s1", W_S1EIK
+        assert list(loss) == ["sdf_on_surf", "sdf_off_surf", "hessian_constraint", "grad_constraint"]
+    elif case == "s2":
+        loss = loss_s2(model, xd, gt, W_S2, 100); mode, w = "s2", W_S2
+        assert list(loss) == ["sdf_on_surf", "std_on_surf"]
+    else:
+        loss = loss_siren(model, xd, gt, W_SIREN); mode, w = "siren", W_SIREN
+        assert list(loss) == ["sdf_on_surf", "sdf_off_surf", "normal_constraint", "grad_constraint"]
+    # the reference loop's usage: += into a (1,1) tensor, .item(), .backward()
+    train_loss = torch.zeros((1, 1), device="cuda:0")
+    for it, l in loss.items():
+        train_loss += l
+        assert isinstance(l.item(), float)
+    train_loss.backward()
+    t_ref, g_ref, _ = O.loss_and_grad(mode, P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), w, 100.0)
+    assert rel([v.item() for v in loss.values()], [float(v) for v in t_ref.values()]) < 2e-5
+    got = np.concatenate([p.grad.detach().reshape(-1).cpu().numpy() for p in model.parameters()])
+    assert rel(got, flat(g_ref)) < 1e-4
+    names = [n for n, _ in model.named_parameters()]
+    assert names[0] == "net.0.0.weight" and names[-1] == "net.8.0.bias"
+
+
+def test_adam_trajectory_follows_reference_fixture(golden_dir):
+    """20 steps of the reference loop (loss dict -> sum -> backward -> torch.optim.Adam) on a 4x64 net must follow
+    the curve the reference itself produced (g3_traj.npz): loss within 1e-4 relative after N steps."""
+    from src.loss_functions import loss_s1, loss_s2
+    G = np.load(os.path.join(golden_dir, "g3_traj.npz"))
+    hidden = list(G["hidden"]); n = int(G["n_points"]); seed = int(G["batch_seed"])
+    for name, fn, w, lr in (("s1eik", loss_s1, W_S1EIK, 1e-4), ("s2", loss_s2, W_S2, 1e-6)):
+        model, _ = make_model(hidden, int(G["param_seed"]))
+        opt = torch.optim.Adam(lr=lr, params=model.parameters())
+        hist = []
+        for t in range(int(G["steps"])):
+            _, (xd, nd, sd) = batch(n, seed, step=t)
+            opt.zero_grad()
+            loss = fn(model, xd, {"normals": nd, "sdf": sd}, w, 100)
+            total = torch.zeros((1, 1), device="cuda:0")
+            for l in loss.values():
+                total += l
+            total.backward()
+            opt.step()
+            hist.append([l.item() for l in loss.values()])
+        hist = np.array(hist)
+        ref = G[f"{name}_f64_hist"]
+        e_hist = np.abs(hist - ref).max() / np.abs(ref).max()
+        e_theta = rel(model.flat_parameters().cpu().numpy(), G[f"{name}_f64_theta"])
+        print(f"{name}: trajectory loss err {e_hist:.2e} theta err {e_theta:.2e} (reference fp32-vs-fp64: "
+              f"{np.abs(G[name + '_f32_hist'] - ref).max() / np.abs(ref).max():.2e})")
+        assert e_hist < 1e-4
+        assert e_theta < 1e-4
+
+
+def test_8x256_trajectory_follows_reference_fixture(golden_dir):
+    from diffudf_amd.engine import TrainEngine, LOSS_S1
+    G = np.load(os.path.join(golden_dir, "g3_traj_8x256.npz"))
+    hidden = list(G["hidden"]); n = int(G["n_points"]); seed = int(G["batch_seed"])
+    theta = torch.from_numpy(synth.flatten_params(synth.siren_params(hidden, seed=int(G["param_seed"])))).cuda()
+    eng = TrainEngine(hidden, theta)
+    hist = []
+    for t in range(int(G["steps"])):
+        _, (xd, nd, sd) = batch(n, seed, step=t)
+        terms = eng.step(LOSS_S1, xd[0], nd[0], sd.reshape(-1), W_S1EIK, 100.0, lr=1e-4)
+        hist.append(terms.cpu().numpy().copy())
+    hist = np.array(hist, dtype=np.float64)
+    ref = G["s1eik_f64_hist"]
+    assert np.abs(hist - ref).max() / np.abs(ref).max() < 1e-4
+    assert rel(theta.cpu().numpy()[G["sample"]], G["s1eik_f64_theta_sample"]) < 1e-4
+
+
+def test_forward_gradient_evaluate_contract(golden_dir):
+    from src.diff_operators import gradient, hessian
+    from src.evaluate import evaluate
+    from src.inverses import inverse
+    from diffudf_amd._lib import DudfError
+    model, P = make_model([256] * 8, 123)
+    G = np.load(os.path.join(golden_dir, "g4_query.npz"))
+    n = int(G["grid_n"])
+    ax = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    out = model(torch.from_numpy(grid)[None].cuda())
+    assert list(out) == ["model_in", "model_out"]
+    xin, y = out.values()
+    assert xin.requires_grad and xin.shape == (1, n ** 3, 3) and y.shape == (1, n ** 3, 1)
+    g = gradient(y, xin)
+    assert g.shape == xin.shape
+    assert rel(y.detach().cpu().numpy()[0], G["values"]) < 2e-5
+    assert rel(g.cpu().numpy()[0], G["gradients"]) < 5e-5
+    with pytest.raises(DudfError):
+        hessian(y, xin)
+    # (M,3) inputs as reference src/render_mc.py:340 uses them
+    y2 = model(torch.from_numpy(grid).cuda())["model_out"]
+    assert y2.shape == (n ** 3, 1) and torch.equal(y2.reshape(-1), y.reshape(-1))
+    grads = np.zeros((n ** 3, 3))
+    vals = evaluate(model, grid, max_batch=500, device=torch.device("cuda:0"), gradients=grads)
+    assert vals.dtype == np.float64 and vals.shape == (n ** 3, 1)
+    assert rel(vals, G["values"]) < 2e-5 and rel(grads, G["gradients"]) < 5e-5
+    assert np.allclose(inverse("tanh", np.abs(vals), 100), G["inv_tanh"], rtol=1e-4, atol=1e-7)
+    with pytest.raises(DudfError):
+        evaluate(model, grid, device=torch.device("cuda:0"), hessians=np.zeros((n ** 3, 3, 3)))
+
+
+def test_custom_loss_through_fields():
+    """A loss written in plain PyTorch on (f, df/dx) trains through the HIP adjoint sweeps."""
+    from diffudf_amd.diff_operators import fields
+    hidden = [64] * 4
+    model, P = make_model(hidden, 11)
+    (x, _, _), (xd, _, _) = batch(300, 11)
+    f, g = fields(model, xd)
+    loss = (f ** 2).sum() * 0.5 + (g * g).sum() * 0.25
+    loss.backward()
+    xs = x.astype(np.float64)
+    y, cache = O.forward(P, xs)
+    gg, rev = O.input_gradient(P, cache)
+    grads, _ = O.param_grad(P, xs, cache, rev, y, 0.5 * gg)
+    got = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in model.parameters()])
+    assert rel(got, flat(grads)) < 1e-4
+    # value-only path: backward through model(x)['model_out'] reaches parameters and the input
+    model.zero_grad()
+    out = model(xd)
+    (out["model_out"] ** 2).sum().backward()
+    grads2, _ = O.param_grad(P, xs, cache, None, 2 * y, None)
+    got2 = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in model.parameters()])
+    assert rel(got2, flat(grads2)) < 1e-4
+    assert rel(out["model_in"].grad.cpu().numpy()[0], 2 * y[:, None] * gg) < 1e-4
+
+
+def test_train_cli_loop_runs(tmp_path):
+    import train
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "train_synth_eikonal.json")))
+    cfg.update({"num_epochs": 6, "s1_epochs": 4, "warmup_epochs": 2, "batch_size": 3000,
+                "checkpoint_path": str(tmp_path), "experiment_name": "t",
+                "network": {"hidden_layer_nodes": [64] * 4, "w0": 30, "pretrained_dict": "None"}})
+    t, meshes = train.setup_train(cfg, 0)
+    assert t > 0 and meshes == []
+    base = tmp_path / "t"
+    sd = torch.load(base / "models" / "model_final.pth")
+    assert list(sd)[:2] == ["net.0.0.weight", "net.0.0.bias"]
+    import pandas as pd
+    df = pd.read_csv(base / "losses.csv", sep=";")
+    assert list(df.columns) == ["sdf_on_surf", "sdf_off_surf", "hessian_constraint", "grad_constraint", "std_on_surf"]
+    assert len(df) == 6 and np.isfinite(df.values).all()
+    assert (base / "params.json").exists()

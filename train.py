@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Training entry point with the reference's CLI and config schema:
+
+    python train.py <config.json> <device-index>                       (reference train.py:450-467)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py <config.json> 0
+
+`setup_train(parameter_dict, cuda_device)` and `train_model_tanh` / `train_model_siren` keep the reference
+contracts (reference train.py:285-448, :146-283, :23-143): same config keys and defaults, the same LR /
+phase schedule (warm-up LR, lr_s1 from `warmup_epochs`, loss_s2 + cosine LR from `s1_epochs`), the same
+`results/<exp>/{models,summaries,reconstructions}` layout, `losses.csv` (sep=';'), `params.json`,
+`model_best.pth` / `model_current.pth` / `model_final.pth` with reference state_dict keys.
+
+What runs underneath is the MI355X path: the loss dict comes from the fused HIP kernels
+(diffudf_amd.loss_functions), the optimizer is torch.optim.Adam over the model's parameters (views of one flat
+buffer), and under torch.distributed every rank takes its stratified share of the batch and the gradients
+are all-reduced over RCCL before the step.
+
+Out of scope here: post-training field slices and marching cubes (`generate_df`,
+`generate_mc`) — `resolution` is accepted and ignored with a message; tensorboard is optional.
+"""
+import argparse
+import copy
+import json
+import os
+import os.path as osp
+import random
+import time
+
+import numpy as np
+import torch
+
+from diffudf_amd.dataset import PointCloud, SyntheticPointCloud
+from diffudf_amd.loss_functions import loss_siren, loss_s1, loss_s2
+from diffudf_amd.model import SIREN
+from diffudf_amd.util import create_output_paths, load_experiment_parameters
+
+try:                                                  # optional, as in many deployments
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:                                     # pragma: no cover
+    SummaryWriter = None
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def _dist():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def _allreduce_grads(model):
+    """Every rank holds its share sum_local/n_global of the gradient: one all-reduce(sum) of the flat buffer."""
+    if not _dist() or torch.distributed.get_world_size() == 1:
+        return
+    grads = [p.grad for p in model.parameters()]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    torch.distributed.all_reduce(flat)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+
+def _is_main():
+    return (not _dist()) or torch.distributed.get_rank() == 0
+
+
+def _train(dataset, model, device, config, schedule):
+    """Shared epoch loop of train_model_tanh / train_model_siren (reference train.py:172-283 / :49-143)."""
+    epochs = config["epochs"]
+    epochs_til_checkpoint = config.get("epochs_to_checkpoint", 0)
+    log_path = config["log_path"]
+    optim = config["optimizer"]
+    model.to(device)
+    summary_path = osp.join(log_path, 'summaries')
+    os.makedirs(summary_path, exist_ok=True)
+    writer = SummaryWriter(summary_path) if (SummaryWriter is not None and _is_main()) else _NullWriter()
+    if _dist():
+        model.dudf_n_global = dataset.n_global        # terms/grads are shares of the GLOBAL mean
+        model.dudf_allreduce = lambda t: torch.distributed.all_reduce(t)
+
+    losses = dict()
+    best_loss = np.inf
+    best_weights = None
+    recon_time = 0
+    start_ttime = time.time()
+    for epoch in range(epochs):
+        loss_fn, loss_weights, current_lr, extra = schedule(epoch)
+        if current_lr is not None:
+            for g in optim.param_groups:
+                g['lr'] = current_lr
+        running_loss = dict()
+        for input_data, normals, sdf in iter(dataset):
+            optim.zero_grad()
+            input_data = input_data.to(device); normals = normals.to(device); sdf = sdf.to(device)
+            loss = loss_fn(model, input_data, {'normals': normals, 'sdf': sdf}, loss_weights, *extra)
+            train_loss = torch.zeros((1, 1), device=device)
+            vals = torch.stack([l.reshape(()) for l in loss.values()]).detach()
+            for l in loss.values():
+                train_loss += l
+            train_loss.backward()
+            _allreduce_grads(model)
+            if _dist():
+                torch.distributed.all_reduce(vals)
+            optim.step()
+            vals = vals.tolist()                       # ONE device->host sync per step (the reference does five)
+            for (it, _), v in zip(loss.items(), vals):
+                running_loss[it] = running_loss.get(it, 0.0) + v
+            writer.add_scalar("train_loss", sum(vals), epoch)
+
+        for it, l in running_loss.items():
+            if it not in losses:
+                losses[it] = [0.] * epochs
+            losses[it][epoch] = l
+            writer.add_scalar(it, l, epoch)
+        epoch_loss = sum(running_loss.values()) / dataset.batchesPerEpoch
+        if _is_main():
+            lr_now = optim.param_groups[0]['lr']
+            print(f"Epoch: {epoch} - Loss: {epoch_loss} - Learning Rate: {lr_now:.3e}")
+
+        start_rtime = time.time()
+        if _is_main():
+            if epoch_loss < best_loss:
+                best_loss = epoch_loss
+                best_weights = copy.deepcopy(model.state_dict())
+                if config.get("save_every_epoch", True):
+                    torch.save(best_weights, osp.join(log_path, "models", "model_best.pth"))
+            if epoch and epochs_til_checkpoint and (not epoch % epochs_til_checkpoint):
+                print(f"Saving model for epoch {epoch}")
+                torch.save(model.state_dict(), osp.join(log_path, "models", f"model_{epoch}.pth"))
+            elif config.get("save_every_epoch", True):
+                torch.save(model.state_dict(), osp.join(log_path, "models", "model_current.pth"))
+        recon_time += time.time() - start_rtime
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    total_training_time = time.time() - start_ttime - recon_time
+    if _is_main() and best_weights is not None:
+        torch.save(best_weights, osp.join(log_path, "models", "model_best.pth"))
+    return losses, best_weights, total_training_time
+
+
+def train_model_tanh(dataset, model, device, config):
+    """gt_mode 'tanh': loss_s1 then loss_s2 (reference train.py:146-283)."""
+    epochs = config["epochs"]
+
+    def schedule(epoch):
+        if epoch >= config['s1_epochs']:
+            if epoch == config['s1_epochs'] and _is_main():
+                print('Starting second step...')
+            lr = 0.5 * (np.cos(epoch / (epochs - config['s1_epochs']) * np.pi) + 1) * config['lr_s2']
+            return loss_s2, config['loss_s2_weights'], lr, (config["alpha"],)
+        lr = config['lr_s1'] if epoch >= config['warmup_epochs'] else config['warmup_lr']
+        return loss_s1, config['loss_s1_weights'], lr, (config["alpha"],)
+
+    return _train(dataset, model, device, config, schedule)
+
+
+def train_model_siren(dataset, model, device, config):
+    """gt_mode 'siren': SIREN's SDF loss at the optimizer's own LR (reference train.py:23-143)."""
+    def schedule(epoch):
+        return loss_siren, config["loss_weights"], None, ()
+
+    return _train(dataset, model, device, config, schedule)
+
+
+def setup_train(parameter_dict, cuda_device):
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py: no GPU visible; the HIP training path has no CPU fallback")
+    rank = world = None
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        cuda_device = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(cuda_device)
+        if not _dist():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", cuda_device))
+        rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+    device = torch.device("cuda", int(cuda_device))
+    seed = 123
+    torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+
+    full_path = create_output_paths(parameter_dict["checkpoint_path"], parameter_dict["experiment_name"], overwrite=False)
+    if _is_main():
+        with open(osp.join(full_path, "params.json"), "w") as fout:
+            json.dump(parameter_dict, fout, indent=4)
+
+    sp = parameter_dict["sampling_percentiles"]
+    if str(parameter_dict["dataset"]).startswith("synthetic"):
+        dataset = SyntheticPointCloud(parameter_dict["batch_size"], sp, parameter_dict["batches_per_epoch"], seed=seed,
+                                      rank=rank or 0, world=world or 1)
+    else:
+        dataset = PointCloud(parameter_dict["dataset"], parameter_dict["batch_size"], sp,
+                             parameter_dict["batches_per_epoch"], device=device,
+                             onlyPCloud=parameter_dict.get('onlyPCloud', False))
+
+    network_params = parameter_dict["network"]
+    model = SIREN(n_in_features=3, n_out_features=1, hidden_layer_config=network_params["hidden_layer_nodes"],
+                  w0=network_params["w0"], ww=network_params.get("ww", None),
+                  activation=network_params.get('activation', 'sine'))
+    if network_params.get('pretrained_dict', 'None') != 'None':
+        model.load_state_dict(torch.load(network_params['pretrained_dict'], map_location=device))
+    if _is_main():
+        print(model)
+    model.to(device)
+    if _dist():                                        # replicas start identical
+        torch.distributed.broadcast(model.flat_parameters(), src=0)
+
+    opt_params = parameter_dict["optimizer"]
+    gt_mode = parameter_dict.get("gt_mode", "tanh")
+    if opt_params["type"] != "adam":
+        raise ValueError('Unknown optimizer')
+    if gt_mode == 'tanh':
+        optimizer = torch.optim.Adam(lr=opt_params["lr_s1"], params=model.parameters())
+        config_dict = {
+            "epochs": parameter_dict["num_epochs"], "s1_epochs": parameter_dict["s1_epochs"],
+            "warmup_epochs": parameter_dict.get("warmup_epochs", 0), "warmup_lr": parameter_dict.get("warmup_lr", 1e-4),
+            "batch_size": parameter_dict["batch_size"], "epochs_to_checkpoint": parameter_dict["epochs_to_checkpoint"],
+            "gt_mode": gt_mode, "log_path": full_path, "optimizer": optimizer,
+            "lr_s1": opt_params["lr_s1"], "lr_s2": opt_params["lr_s2"],
+            "loss_s1_weights": parameter_dict["loss_s1_weights"], "loss_s2_weights": parameter_dict["loss_s2_weights"],
+            "alpha": parameter_dict["alpha"], "resolution": parameter_dict.get("resolution", 256),
+            "save_every_epoch": parameter_dict.get("save_every_epoch", True),
+        }
+        losses, best_weights, training_time = train_model_tanh(dataset, model, device, config_dict)
+    elif gt_mode == 'siren':
+        optimizer = torch.optim.Adam(lr=opt_params["lr"], params=model.parameters())
+        config_dict = {
+            "epochs": parameter_dict["num_epochs"], "batch_size": parameter_dict["batch_size"],
+            "epochs_to_checkpoint": parameter_dict["epochs_to_checkpoint"], "gt_mode": gt_mode, "log_path": full_path,
+            "optimizer": optimizer, "loss_weights": parameter_dict["loss_weights"],
+            "alpha": parameter_dict.get("alpha", 100), "resolution": parameter_dict.get("resolution", 256),
+            "save_every_epoch": parameter_dict.get("save_every_epoch", True),
+        }
+        losses, best_weights, training_time = train_model_siren(dataset, model, device, config_dict)
+    else:
+        raise ValueError('gt_mode not valid')
+
+    if _is_main():
+        import pandas as pd
+        pd.DataFrame.from_dict(losses).to_csv(osp.join(full_path, "losses.csv"), sep=";", index=None)
+        torch.save(model.state_dict(), osp.join(full_path, "models", "model_final.pth"))
+        n_pts = dataset.n_global * dataset.batchesPerEpoch * parameter_dict["num_epochs"]
+        print(f"training time {training_time:.2f} s  ({n_pts / training_time:.3e} points/s)")
+        if parameter_dict.get("resolution", 256) != 0:
+            print("note: post-training field slices / marching cubes (generate_df, generate_mc) are outside this "
+                  "build's scope (SURVEY.md §8); checkpoints are in", osp.join(full_path, "models"))
+    return training_time, []
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser(usage="python train.py path_to_experiments.json cuda_device")
+    p.add_argument("experiment_path", type=str, help="Path to the JSON experiment description file")
+    p.add_argument("device", type=int, help="Cuda device")
+    args = p.parse_args()
+    parameter_dict = load_experiment_parameters(args.experiment_path)
+    if not bool(parameter_dict):
+        raise ValueError("JSON experiment not found")
+    setup_train(parameter_dict, args.device)
+    if _dist():
+        torch.distributed.destroy_process_group()
