@@ -25,56 +25,107 @@
 
 namespace {
 
+constexpr int NW = 4;                             // waves per workgroup (one per SIMD); two workgroups share a CU
+constexpr int TILE = NW * 16;                     // points per workgroup pass
+
 template <int H>
 struct Geo {
     static constexpr int NT = H / 16;             // 16-feature tiles per activation vector
     static constexpr int NCH = H / 32;            // 32-row weight chunks per layer
     static constexpr int LDW = H + 4;             // padded LDS row stride in floats
     static constexpr int BUF = 32 * LDW;          // floats per LDS chunk buffer
-    static constexpr int NTHR = 512;
+    static constexpr int NTHR = 64 * NW;
     static constexpr int F4 = 8 * H;              // float4 per chunk
-    static constexpr int NSTG = (F4 + NTHR - 1) / NTHR;
+    static constexpr bool DMA = (H == 256);       // one LDS-DMA wave-instruction == one 1 KiB weight row
+    static constexpr int NSTG = DMA ? 1 : (F4 + NTHR - 1) / NTHR;
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- weight chunk staging: rows [32r, 32r+32) of a row-major HxH matrix -> LDS buffer with padded rows -----
+// H == 256: LDS-DMA (global_load_lds_dwordx4): each wave-instruction moves one whole 1 KiB row, so the rows
+//           can keep their +4-float padding; no staging registers, no ds_write.  Completion is the issuing
+//           wave's vmcnt, published to the other waves by the chunk barrier.
+// H <  256: global_load_dwordx4 -> registers (issue) ... ds_write_b128 (commit) one chunk later.
 template <int H>
-__device__ __forceinline__ void stage_issue(const float* __restrict__ M, int r, f32x4 (&stg)[Geo<H>::NSTG], int tid) {
+__device__ __forceinline__ void stage_issue(const float* __restrict__ M, int r, float* buf,
+                                            f32x4 (&stg)[Geo<H>::NSTG], int tid) {
     using G = Geo<H>;
+    if constexpr (G::DMA) {
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int j = 0; j < G::NSTG; ++j) {
-        const int f = tid + G::NTHR * j;
-        if (f < G::F4) {
-            const int row = f / (H / 4), c4 = f % (H / 4);
-            stg[j] = *reinterpret_cast<const f32x4*>(M + (size_t)(32 * r + row) * H + 4 * c4);
+        for (int i = 0; i < 32 / NW; ++i) {
+            const int row = wave * (32 / NW) + i;
+            const float* g = M + (size_t)(32 * r + row) * H + lane * 4;
+            // LDS byte address of the row, wave-uniform -> M0.  Inline asm on purpose: a builtin LDS-DMA makes
+            // hipcc wait vmcnt(0) before the next ds_read of ANY LDS address (it cannot prove the two chunk
+            // buffers distinct), which would expose the whole DMA latency at every chunk.  The matching wait is
+            // dma_wait() in front of the chunk barrier.
+            const unsigned l = __builtin_amdgcn_readfirstlane(
+                (unsigned)(size_t)(__attribute__((address_space(3))) float*)(buf + row * G::LDW));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < G::NSTG; ++j) {
+            const int f = tid + G::NTHR * j;
+            if (G::F4 % G::NTHR == 0 || f < G::F4) {
+                const int row = f / (H / 4), c4 = f % (H / 4);
+                stg[j] = *reinterpret_cast<const f32x4*>(M + (size_t)(32 * r + row) * H + 4 * c4);
+            }
         }
     }
+}
+
+// The LDS-DMA pieces this wave issued have landed.  vmcnt counts every vector-memory operation of the wave in
+// issue order, and the asm statements pin that order: after the DMA pieces of a chunk come exactly
+// younger_ops<SW,FL>() compiler-issued operations (operand loads of the next tail + stash stores of the current
+// one), so waiting for "all but that many" retires the DMA while those stay in flight.
+// tests/test_isa_contract.py counts the instructions in the built code object and fails if this drifts.
+template <int SW, int FL>
+constexpr int younger_ops() {
+    return SW == SWEEP_FWD ? 2 + 2 * ((FL & 1) + ((FL >> 1) & 1))      // 2 bias loads + s/c stores of 2 tiles
+         : SW == SWEEP_REV ? ((FL & 1) ? 4 + 4 : 2)                     // c,s loads + q,r stores | c loads
+         : SW == SWEEP_ADJ_FWD ? 4 + 4                                  // c,r loads + A,e stores
+         : ((FL & 1) ? 4 + 2 : 2 + 2);                                  // c(,e) loads + zbar stores
+}
+template <int H, int N>
+__device__ __forceinline__ void dma_wait() {
+    if constexpr (Geo<H>::DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
 template <int H>
 __device__ __forceinline__ void stage_commit(float* buf, const f32x4 (&stg)[Geo<H>::NSTG], int tid) {
     using G = Geo<H>;
+    if constexpr (!G::DMA) {
 #pragma unroll
-    for (int j = 0; j < G::NSTG; ++j) {
-        const int f = tid + G::NTHR * j;
-        if (f < G::F4) {
-            const int row = f / (H / 4), c4 = f % (H / 4);
-            *reinterpret_cast<f32x4*>(buf + row * G::LDW + 4 * c4) = stg[j];
+        for (int j = 0; j < G::NSTG; ++j) {
+            const int f = tid + G::NTHR * j;
+            if (G::F4 % G::NTHR == 0 || f < G::F4) {
+                const int row = f / (H / 4), c4 = f % (H / 4);
+                *reinterpret_cast<f32x4*>(buf + row * G::LDW + 4 * c4) = stg[j];
+            }
         }
     }
 }
 
-// Elementwise tail of one 16-feature x 16-point tile.  `so` = float offset of this lane's 16-byte
-// granule inside a stash array (layer, tile, quarter, point already folded in).
 // Stash addressing: `ub` is a WAVE-UNIFORM float offset (layer and tile folded in, lives in SGPRs),
 // `vo` the lane's 32-bit float offset ((quarter*np + point)*4): global_load/store take the saddr form
 // and no per-tile 64-bit address is kept in VGPRs.
 #define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>((arr) + (ub) + (vo))
 #define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>((arr) + (ub) + (vo))
 
-template <int SW>
+// Elementwise tail of one 16-feature x 16-point tile.
+// FL (compile-time, so the tail stays one basic block that can be interleaved with MFMAs):
+//   SWEEP_FWD: bit0 = stash s_l, bit1 = stash c_l;  SWEEP_REV: bit0 = training (stash q_l, r_l);
+//   SWEEP_ADJ_REV: bit0 = e_l exists (df/dx terms present)
+template <int SW, int FL>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, int64_t ub, unsigned vo) {
     f32x4 out;
     if constexpr (SW == SWEEP_FWD) {
@@ -85,19 +136,19 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             dudf_sincos(a.w0 * acc[t], &sv, &cv);
             s[t] = sv; c[t] = cv;
         }
-        if (a.store_s) *DUDF_AT(a.S, ub, vo) = s;
-        if (a.store_c) *DUDF_AT(a.C, ub, vo) = c;
+        if constexpr (FL & 1) *DUDF_AT(a.S, ub, vo) = s;
+        if constexpr (FL & 2) *DUDF_AT(a.C, ub, vo) = c;
         out = s;
     } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
         out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
-        if (a.train) {
+        if constexpr (FL & 1) {
             *DUDF_AT(a.Q, ub, vo) = out;
             *DUDF_AT(a.R, ub, vo) = (a.w0 * a.w0) * o2 * acc;   // r_l = w0^2 s_l a_l
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
         *DUDF_AT(a.A, ub, vo) = out;
-        *DUDF_AT(a.E, ub, vo) = o2 * acc;                       // e_l = r_l Q_l
+        *DUDF_AT(a.E, ub, vo) = o2 * acc;            // e_l = r_l Q_l
     } else {                                         // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
         *DUDF_AT(a.Z, ub, vo) = out;
@@ -105,29 +156,37 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
     return out;
 }
 
-template <int SW>
+template <int SW, int FL>
 __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, unsigned vo, f32x4& o1, f32x4& o2) {
     if constexpr (SW == SWEEP_REV) {
         o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = a.train ? *DUDF_CAT(a.S, ub, vo) : f32x4{0, 0, 0, 0};
+        o2 = (FL & 1) ? *DUDF_CAT(a.S, ub, vo) : f32x4{0, 0, 0, 0};
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
         o1 = *DUDF_CAT(a.C, ub, vo);
         o2 = *DUDF_CAT(a.R, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
         o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = a.have_e ? *DUDF_CAT(a.E, ub, vo) : f32x4{0, 0, 0, 0};   // no df/dx terms (loss_s2): e_l == 0
+        o2 = (FL & 1) ? *DUDF_CAT(a.E, ub, vo) : f32x4{0, 0, 0, 0};   // no df/dx terms (loss_s2): e_l == 0
     } else {
         o1 = f32x4{0, 0, 0, 0}; o2 = o1;
     }
 }
 
-template <int H, int SW>
-__global__ __launch_bounds__(512, 2) void sweep_kernel(SweepArgs a) {
+// Two finished accumulator tiles whose elementwise tail has not run yet.  The tail of chunk r-1 is executed in
+// the middle of chunk r's MFMA stream (same basic block), so sin/cos, stash traffic and MFMAs overlap inside
+// one wave instead of serialising at every chunk barrier.
+struct Pending {
+    f32x4 acc0, acc1, o1a, o2a, o1b, o2b;
+    int64_t ub0, ub1;
+};
+
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
     using G = Geo<H>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int ntiles = (int)(a.np / DUDF_TILE_PTS);
+    const int ntiles = (int)(a.np / TILE);
     const int nhid = a.L - 1;                          // hidden x hidden layers
     constexpr bool kFwdDir = (SW == SWEEP_FWD || SW == SWEEP_ADJ_FWD);
 
@@ -136,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void sweep_kernel(SweepArgs a) {
     unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t p = (int64_t)tile * DUDF_TILE_PTS + wave * 16 + li;
+        const int64_t p = (int64_t)tile * TILE + wave * 16 + li;
         const bool valid = p < a.n;
         // j-th hidden matrix this sweep multiplies by, and the 0-based layer index its output belongs to
         auto matrix = [&](int j) -> const float* {
@@ -149,79 +208,121 @@ __global__ __launch_bounds__(512, 2) void sweep_kernel(SweepArgs a) {
         };
         const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 4);           // this lane's granule
 
-        if (nhid > 0) stage_issue<H>(matrix(0), 0, stg, tid);
+        // every wave of the workgroup is past its last LDS read of the previous tile before buffers are refilled
+        __syncthreads();
+        if (nhid > 0) stage_issue<H>(matrix(0), 0, lds + (gc & 1) * G::BUF, stg, tid);
 
-        // ------------------------------ prologue: fills in[] ------------------------------
-        if constexpr (SW == SWEEP_FWD || SW == SWEEP_ADJ_FWD) {
-            float b;
+        // ------------------------------ prologue: first activation vector ------------------------------
+        Pending pend;
+        {
+            float b = 0.f, yb = 1.f;
             if constexpr (SW == SWEEP_FWD) b = (q < 3) ? (valid ? a.x[p * 3 + q] : 0.f) : 1.f;   // k=3 carries the bias
-            else b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;                                          // A_0 = gbar
-#pragma unroll
-            for (int T = 0; T < G::NT; ++T) {
-                const int64_t ub = stash_base(0, T);
-                f32x4 o1, o2;
-                epilogue_loads<SW>(a, ub, vo, o1, o2);
-                const float w = a.w1b[(16 * T + li) * 4 + q];
-                f32x4 acc = mfma16(w, b, f32x4{0, 0, 0, 0});
-                in[T] = epilogue<SW>(a, acc, o1, o2, ub, vo);
-            }
-        } else {
-            float yb = 1.f;
+            if constexpr (SW == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;            // A_0 = gbar
             if constexpr (SW == SWEEP_ADJ_REV) yb = a.ybar[p];
+            const int l0 = kFwdDir ? 0 : a.L - 1;
 #pragma unroll
             for (int T = 0; T < G::NT; ++T) {
-                const int64_t ub = stash_base(a.L - 1, T);
-                f32x4 o1, o2;
-                epilogue_loads<SW>(a, ub, vo, o1, o2);
-                f32x4 acc = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
-                in[T] = epilogue<SW>(a, acc, o1, o2, ub, vo);
+                const int64_t ub = stash_base(l0, T);
+                f32x4 o1, o2, acc;
+                epilogue_loads<SW, FL>(a, ub, vo, o1, o2);
+                if constexpr (kFwdDir) {
+                    acc = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
+                } else {
+                    acc = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
+                }
+                if (T < G::NT - 2) {
+                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, ub, vo);
+                } else if (T == G::NT - 2) {
+                    pend.acc0 = acc; pend.o1a = o1; pend.o2a = o2; pend.ub0 = ub;
+                } else {
+                    pend.acc1 = acc; pend.o1b = o1; pend.o2b = o2; pend.ub1 = ub;
+                }
             }
         }
 
         // ------------------------------ hidden x hidden layers ------------------------------
+        // Order inside a chunk (it matters: hipcc does not see the asm LDS-DMA in its vmcnt bookkeeping, so no
+        // compiler-visible vector-memory wait may sit between a DMA issue and dma_wait(), or it drains the DMA):
+        //   first k-tile MFMAs -> tail of the previous chunk (waits its operands, issues its stash stores)
+        //   -> DMA issue for the next chunk -> operand/bias loads for the next tail -> remaining MFMAs
+        //   -> dma_wait + barrier.
+        f32x4 bias0 = {0, 0, 0, 0}, bias1 = {0, 0, 0, 0};
+        if constexpr (SW == SWEEP_FWD) {
+            if (nhid > 0) {
+                const float* bias = matrix(0) + (size_t)H * H;
+                bias0 = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+                bias1 = *reinterpret_cast<const f32x4*>(bias + 16 + 4 * q);
+            }
+        }
         for (int j = 0; j < nhid; ++j) {
             const float* M = matrix(j);
             const float* Mn = (j + 1 < nhid) ? matrix(j + 1) : nullptr;
             const int lo = out_layer(j);
             stage_commit<H>(lds + (gc & 1) * G::BUF, stg, tid);
+            if (j == 0) dma_wait<H, 0>();               // the prologue's loads and stores sit behind this DMA
+            else dma_wait<H, younger_ops<SW, FL>()>();
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < G::NCH; ++r) {
-                if (r + 1 < G::NCH) stage_issue<H>(M, r + 1, stg, tid);
-                else if (Mn) stage_issue<H>(Mn, 0, stg, tid);
-                const int64_t ub0 = stash_base(lo, 2 * r), ub1 = stash_base(lo, 2 * r + 1);
-                f32x4 p0, p1, p2, p3;
-                epilogue_loads<SW>(a, ub0, vo, p0, p1);
-                epilogue_loads<SW>(a, ub1, vo, p2, p3);
-                f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-                if constexpr (SW == SWEEP_FWD) {
-                    const float* bias = M + (size_t)H * H;
-                    acc0 = *reinterpret_cast<const f32x4*>(bias + 32 * r + 4 * q);
-                    acc1 = *reinterpret_cast<const f32x4*>(bias + 32 * r + 16 + 4 * q);
-                }
+                Pending cur;
+                cur.ub0 = stash_base(lo, 2 * r); cur.ub1 = stash_base(lo, 2 * r + 1);
+                // the bias loads issued during the previous chunk have landed: make the compiler wait for them
+                // here, before this chunk's LDS-DMA goes in flight
+                if constexpr (SW == SWEEP_FWD) asm volatile("" : "+v"(bias0), "+v"(bias1));
+                cur.acc0 = bias0; cur.acc1 = bias1;
                 const float* bp = lds + (gc & 1) * G::BUF + li * G::LDW + 4 * q;
+                auto chunk_head = [&]() {
+                    // operands of the previous chunk's tail have landed: the compiler puts its own vmcnt wait
+                    // HERE, while no LDS-DMA of this chunk is in flight yet
+                    if constexpr (SW != SWEEP_FWD)
+                        asm volatile("" : "+v"(pend.o1a), "+v"(pend.o2a), "+v"(pend.o1b), "+v"(pend.o2b));
+                    float* nbuf = lds + ((gc + 1) & 1) * G::BUF;
+                    if (r + 1 < G::NCH) stage_issue<H>(M, r + 1, nbuf, stg, tid);
+                    else if (Mn) stage_issue<H>(Mn, 0, nbuf, stg, tid);
+                    epilogue_loads<SW, FL>(a, cur.ub0, vo, cur.o1a, cur.o2a);
+                    epilogue_loads<SW, FL>(a, cur.ub1, vo, cur.o1b, cur.o2b);
+                    if constexpr (SW == SWEEP_FWD) {
+                        const float* bias = (r + 1 < G::NCH) ? M + (size_t)H * H + 32 * (r + 1)
+                                                             : (Mn ? Mn + (size_t)H * H : M + (size_t)H * H);
+                        bias0 = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+                        bias1 = *reinterpret_cast<const f32x4*>(bias + 16 + 4 * q);
+                    }
+                    // loads stay up here; everything below (MFMAs, the tail's VALU and stash stores) is one
+                    // freely interleavable region
+                    __builtin_amdgcn_sched_barrier(0);
+                    // tail of the previous chunk's two tiles (the previous layer's last two when r == 0)
+                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.ub0, vo);
+                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.ub1, vo);
+                    if (r == 0) { in[G::NT - 2] = e0; in[G::NT - 1] = e1; }
+                    else { nxt[2 * r - 2] = e0; nxt[2 * r - 1] = e1; }
+                };
 #pragma unroll
                 for (int T = 0; T < G::NT; ++T) {
+                    if (G::NT <= 2 && T == 0) chunk_head();     // tiny nets: k-tile 0 itself is one of the pending tiles
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(bp + 16 * T);
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(bp + 16 * G::LDW + 16 * T);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        acc0 = mfma16(a0[t], in[T][t], acc0);
-                        acc1 = mfma16(a1[t], in[T][t], acc1);
+                        cur.acc0 = mfma16(a0[t], in[T][t], cur.acc0);
+                        cur.acc1 = mfma16(a1[t], in[T][t], cur.acc1);
                     }
+                    if (G::NT > 2 && T == 0) chunk_head();
                 }
-                nxt[2 * r] = epilogue<SW>(a, acc0, p0, p1, ub0, vo);
-                nxt[2 * r + 1] = epilogue<SW>(a, acc1, p2, p3, ub1, vo);
+                pend = cur;
                 if (r + 1 < G::NCH) {
                     ++gc;
                     stage_commit<H>(lds + (gc & 1) * G::BUF, stg, tid);
+                    dma_wait<H, younger_ops<SW, FL>()>();
                     __syncthreads();
                 }
             }
             ++gc;
 #pragma unroll
-            for (int T = 0; T < G::NT; ++T) in[T] = nxt[T];
+            for (int T = 0; T < G::NT - 2; ++T) in[T] = nxt[T];
         }
+        // flush the last pending pair
+        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.ub0, vo);
+        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.ub1, vo);
 
         // ------------------------------ tail ------------------------------
         if constexpr (SW == SWEEP_FWD) {                // y = W_out s_L + b_out
@@ -251,26 +352,35 @@ template <int H>
 int launch_h(int which, const SweepArgs& a, hipStream_t st) {
     using G = Geo<H>;
     const size_t smem = 2 * G::BUF * sizeof(float);
-    const int ntiles = (int)(a.np / DUDF_TILE_PTS);
-    int grid = ntiles < 256 ? ntiles : 256;
+    const int ntiles = (int)(a.np / TILE);
+    int grid = ntiles < 512 ? ntiles : 512;            // two 4-wave workgroups per CU
     if (grid < 1) grid = 1;
     hipError_t e = hipSuccess;
-#define DUDF_GO(SW)                                                                                         \
+#define DUDF_GO(SW, FL)                                                                                     \
     do {                                                                                                    \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<H, SW>),                    \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<H, SW, FL>),                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
             if (e != hipSuccess) return (int)e;                                                             \
             attr_done = true;                                                                               \
         }                                                                                                   \
-        hipLaunchKernelGGL((sweep_kernel<H, SW>), dim3(grid), dim3(G::NTHR), smem, st, a);                  \
+        hipLaunchKernelGGL((sweep_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);              \
     } while (0)
     switch (which) {
-        case SWEEP_FWD: DUDF_GO(SWEEP_FWD); break;
-        case SWEEP_REV: DUDF_GO(SWEEP_REV); break;
-        case SWEEP_ADJ_FWD: DUDF_GO(SWEEP_ADJ_FWD); break;
-        case SWEEP_ADJ_REV: DUDF_GO(SWEEP_ADJ_REV); break;
+        case SWEEP_FWD:
+            if (a.store_s && a.store_c) DUDF_GO(SWEEP_FWD, 3);
+            else if (a.store_c) DUDF_GO(SWEEP_FWD, 2);
+            else if (!a.store_s) DUDF_GO(SWEEP_FWD, 0);
+            else return DUDF_E_BADMODE;
+            break;
+        case SWEEP_REV:
+            if (a.train) DUDF_GO(SWEEP_REV, 1); else DUDF_GO(SWEEP_REV, 0);
+            break;
+        case SWEEP_ADJ_FWD: DUDF_GO(SWEEP_ADJ_FWD, 0); break;
+        case SWEEP_ADJ_REV:
+            if (a.have_e) DUDF_GO(SWEEP_ADJ_REV, 1); else DUDF_GO(SWEEP_ADJ_REV, 0);
+            break;
         default: return DUDF_E_BADMODE;
     }
 #undef DUDF_GO

@@ -49,9 +49,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     constexpr int TILE = FQ * KTP * 4;              // floats per staged operand
     constexpr int F4 = FQ * KT;                     // float4 per operand per stage
     constexpr int NLD = (F4 + NTHR - 1) / NTHR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ldsX = lds;
-    float* ldsY = lds + TILE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2 buffers][X tile | Y tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo = wave / W::WI, wi = wave % W::WI;
@@ -62,15 +60,14 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     const int s1 = (int)((int64_t)a.steps_total * (blockIdx.y + 1) / nsplit);
 
     f32x16 acc[W::MT][W::NTL];
-    f32x16 accb[W::MT];
+    float bsum[W::MT];                              // bias gradient: running row sums of zbar (VALU, beside the MFMAs)
 #pragma unroll
     for (int m = 0; m < W::MT; ++m) {
 #pragma unroll
         for (int n = 0; n < W::NTL; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accb[m][e] = 0.f;
+        bsum[m] = 0.f;
     }
 
     // pair 0: X = q_l (layer index j+1), Y = A_{l-1} (index j);  pair 1: X = zbar_l, Y = s_{l-1}
@@ -84,7 +81,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int f = tid + NTHR * u;
-            if (f < F4) {
+            if (F4 % NTHR == 0 || f < F4) {
                 const int fq = f / KT, pt = f % KT;
                 const int64_t off = ((int64_t)fq * a.np + (int64_t)step * KT + pt) * 4;
                 rx[u] = *reinterpret_cast<const f32x4*>((pair ? X1 : X0) + off);
@@ -92,14 +89,14 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](float* buf) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int f = tid + NTHR * u;
-            if (f < F4) {
+            if (F4 % NTHR == 0 || f < F4) {
                 const int fq = f / KT, pt = f % KT;
-                *reinterpret_cast<f32x4*>(ldsX + (fq * KTP + pt) * 4) = rx[u];
-                *reinterpret_cast<f32x4*>(ldsY + (fq * KTP + pt) * 4) = ry[u];
+                *reinterpret_cast<f32x4*>(buf + (fq * KTP + pt) * 4) = rx[u];
+                *reinterpret_cast<f32x4*>(buf + TILE + (fq * KTP + pt) * 4) = ry[u];
             }
         }
     };
@@ -108,25 +105,26 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     const int nit = npair * (s1 - s0);              // (step, pair) iterations
     auto pair_of = [&](int it) { return a.have_g ? (it & 1) : 1; };
     auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
-    if (nit > 0) issue(pair_of(0), step_of(0));
+    if (nit > 0) {
+        issue(pair_of(0), step_of(0));
+        commit(lds);
+    }
+    __syncthreads();
     for (int it = 0; it < nit; ++it) {
-        const int pair = pair_of(it);
-        __syncthreads();                            // previous stage fully consumed
-        commit();
-        __syncthreads();
-        if (it + 1 < nit) issue(pair_of(it + 1), step_of(it + 1));
-        // feature row of this lane inside the operand tiles
+        const float* buf = lds + (it & 1) * 2 * TILE;
+        if (it + 1 < nit) issue(pair_of(it + 1), step_of(it + 1));      // next stage: global -> registers
+        const float bflag = (pair_of(it) == 1 && wi == 0) ? 1.f : 0.f;
         const float* xa[W::MT];
         const float* yb[W::NTL];
 #pragma unroll
         for (int m = 0; m < W::MT; ++m) {
             const int feat = (wo * W::MT + m) * 32 + l32;
-            xa[m] = ldsX + ((feat >> 2) * KTP) * 4 + (feat & 3);
+            xa[m] = buf + ((feat >> 2) * KTP) * 4 + (feat & 3);
         }
 #pragma unroll
         for (int n = 0; n < W::NTL; ++n) {
             const int feat = (wi * W::NTL + n) * 32 + l32;
-            yb[n] = ldsY + ((feat >> 2) * KTP) * 4 + (feat & 3);
+            yb[n] = buf + TILE + ((feat >> 2) * KTP) * 4 + (feat & 3);
         }
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
@@ -140,9 +138,12 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
             for (int m = 0; m < W::MT; ++m) {
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) acc[m][n] = mfma32(av[m], bv[n], acc[m][n]);
-                if (pair == 1 && wi == 0) accb[m] = mfma32(av[m], 1.0f, accb[m]);
+                bsum[m] = fmaf(av[m], bflag, bsum[m]);
             }
         }
+        // the other buffer was last read in iteration it-1 and every wave is past that iteration's barrier
+        if (it + 1 < nit) commit(lds + ((it + 1) & 1) * 2 * TILE);
+        __syncthreads();
     }
 
     // D layout 32x32: col = lane&31 (input index i), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output index o)
@@ -159,8 +160,10 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
                     const int i = (wi * W::NTL + n) * 32 + l32;
                     atomicAdd(dW + (int64_t)o * H + i, acc[m][n][e]);
                 }
-                if (wi == 0 && l32 == 0) atomicAdd(dB + o, accb[m][e]);
             }
+            // lane (l32, hh) summed zbar[feature l32] over the points of parity hh
+            const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (wi == 0 && hh == 0) atomicAdd(dB + (wo * W::MT + m) * 32 + l32, tot);
         }
     }
 }
@@ -192,7 +195,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
     const float* Z0 = a.Z;
     const float* AL = a.A + (int64_t)(a.L - 1) * a.stash_layer;
     const float* SL = a.S + (int64_t)(a.L - 1) * a.stash_layer;
-    for (int fq = wave; fq < FQ; fq += 4) {
+    const int fq_per = (FQ + gridDim.y - 1) / gridDim.y;
+    const int fq_lo = blockIdx.y * fq_per, fq_hi = (fq_lo + fq_per < FQ) ? fq_lo + fq_per : FQ;
+    for (int fq = fq_lo + wave; fq < fq_hi; fq += 4) {
         float w1[4][3], b1[4], wo[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { b1[c] = 0.f; wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = 0.f; }
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
             }
         }
     }
-    if (wave == 0) {                                                  // db_out = sum ybar
+    if (wave == 0 && blockIdx.y == 0) {                               // db_out = sum ybar
         float s = 0.f;
         for (int64_t p = p0 + lane; p < p1; p += 64) s += a.ybar[p];
         s = wave_sum(s);
@@ -245,10 +250,10 @@ template <int H>
 int launch_hidden(const WgradArgs& a, hipStream_t st) {
     using W = WG<H>;
     constexpr int NTHR = 64 * W::WO * W::WI;
-    const size_t smem = 2 * (size_t)(H / 4) * KTP * 4 * sizeof(float);
+    const size_t smem = 4 * (size_t)(H / 4) * KTP * 4 * sizeof(float);   // 2 buffers x (X tile + Y tile)
     const int nl = a.L - 1;
     if (nl <= 0) return 0;
-    int nsplit = (512 + nl - 1) / nl;                    // ~2 workgroups per CU across the layers
+    int nsplit = 256 / nl;                               // one resident workgroup per CU, a single round
     if (nsplit > a.steps_total) nsplit = a.steps_total;
     if (nsplit < 1) nsplit = 1;
     static bool attr_done = false;
@@ -289,6 +294,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dt
     s.pts_per_block = 512;
     const int grid = (int)((lo.np + s.pts_per_block - 1) / s.pts_per_block);
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
-    hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid), dim3(256), 0, st, s);
+    const int gy = (lo.H / 4 >= 16) ? 4 : 1;
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid, gy), dim3(256), 0, st, s);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,52 @@
+# coding: utf-8
+"""Static check of the built sweep kernels' instruction streams (helper for tests/test_isa_contract.py).
+
+The H=256 sweep kernels stage weights with inline-asm LDS-DMA that hipcc does not count, and wait for it with
+hand-written counted `s_waitcnt vmcnt(N)`.  N must equal the number of compiler-issued vector-memory
+instructions between the last DMA piece and that wait.  This parses the assembly hipcc emits for
+dudf_sweep.hip and returns, per kernel, the list of (counted, N) pairs.
+"""
+import re
+import subprocess
+import sys
+
+
+def emit_asm(src, out):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S",
+                    "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+
+
+def analyse(asm_path):
+    txt = open(asm_path).read()
+    out = {}
+    for m in re.finditer(r"^(_ZN\w*sweep_kernelILi256ELi(\d)ELi(\d)E\w*):[^\n]*$", txt, re.M):
+        end = txt.index("s_endpgm", m.end())
+        body = txt[m.end():end]
+        pairs, drains, cnt, scratch, in_asm = [], [], None, 0, False
+        for ln in body.split("\n"):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            if t.startswith("scratch_"):
+                scratch += 1
+            if t.startswith("global_load_lds"):
+                cnt = 0
+            elif re.match(r"(global_load|global_store|global_atomic|buffer_|scratch_|flat_)", t):
+                if cnt is not None:
+                    cnt += 1
+            elif t.startswith("s_waitcnt") and "vmcnt" in t and cnt is not None:
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                if in_asm:                       # the hand-written dma_wait
+                    pairs.append((cnt, n))
+                    cnt = None
+                else:                            # compiler wait while a DMA is in flight: legal, may drain it early
+                    drains.append((cnt, n))
+        out[(int(m.group(2)), int(m.group(3)))] = {"pairs": pairs, "drains": drains, "scratch": scratch}
+    return out
+
+
+if __name__ == "__main__":
+    for k, v in sorted(analyse(sys.argv[1]).items()):
+        print(k, v["scratch"], v["pairs"], "drains:", v["drains"])
