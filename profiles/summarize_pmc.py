@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Aggregate rocprofv3 --pmc counter_collection CSVs (one directory per pass) into a per-kernel summary and
+the per-launch HBM traffic file bench.py reads (profiles/hbm_traffic.json).
+
+    python profiles/summarize_pmc.py gpurun_out/pmc_* --tag r01_b
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB-like units of
+1024 B, collected in SEPARATE passes; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming
+reads (16 B/lane), which is every read these kernels make, so it is doubled; WRITE_SIZE is exact for 16-B stores
+and float atomics.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import statistics as st
+import sys
+
+NAMES = {"<256, 0, 3>": "sweep_fwd", "<256, 1, 1>": "sweep_rev", "<256, 2, 0>": "sweep_adj_fwd",
+         "<256, 3, 1>": "sweep_adj_rev"}
+
+
+def kname(k):
+    if "sweep_kernel" in k:
+        sig = k.split("sweep_kernel")[1].split("(")[0]
+        return NAMES.get(sig, "sweep" + sig)
+    for n in ("wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel", "pack_kernel"):
+        if n in k:
+            return n.replace("_kernel", "")
+    return None
+
+
+def main():
+    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "pmc"
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = kname(r["Kernel_Name"])
+                if k is None:
+                    continue
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                agg[k]["duration_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out, traffic = {}, {}
+    for k, v in sorted(agg.items()):
+        m = {c: st.mean(x) for c, x in v.items()}
+        m["launches_profiled"] = len(v["duration_us"])
+        if "GRBM_GUI_ACTIVE" in m:
+            m["clock_ghz"] = m["GRBM_GUI_ACTIVE"] / 8 / st.mean(v["duration_us"]) / 1e3
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            m["hbm_read_bytes"] = m["FETCH_SIZE"] * 1024 * 2
+            m["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
+            traffic[k] = {"hbm_bytes_per_launch": m["hbm_read_bytes"] + m["hbm_write_bytes"],
+                          "read": m["hbm_read_bytes"], "write": m["hbm_write_bytes"],
+                          "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "
+                                    f"MI355X_MICROARCH.md; profiles/{tag}_pmc_summary.json"}
+        out[k] = {c: (round(x, 3) if isinstance(x, float) else x) for c, x in m.items()}
+    here = os.path.dirname(os.path.abspath(__file__))
+    json.dump(out, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    json.dump(traffic, open(os.path.join(here, "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    for k, m in out.items():
+        print(k, {c: m[c] for c in ("duration_us", "clock_ghz", "hbm_read_bytes", "hbm_write_bytes") if c in m})
+
+
+if __name__ == "__main__":
+    main()
