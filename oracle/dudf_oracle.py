@@ -147,6 +147,19 @@ def loss_s1_terms(y, g, H, normals, sdf, weights, alpha, xp=np):
         t_h = xp.where(on, 1.0 - xp.abs(cs), zero)                    # principal_curvature_alignment :45-53
         out["hessian_constraint"] = t_h.mean() * weights[2]
         cot["lam"], cot["V"], cot["cos"] = lam, V, cs
+        # cotangent of the normal n = V[...,2], then through eigh:
+        #   nbar = -(w2/N) sign(cos) [u=0] ( m/(|m||n|) - cos n/|n|^2 )
+        #   Hbar = sum_{j=0,1} (v_j . nbar)/(lam_2 - lam_j) * 1/2 (v_j n^T + n v_j^T)      (symmetric, all 9 entries)
+        mn = xp.clip(_norm(normals, xp), 1e-8, None)
+        nn = xp.clip(_norm(n, xp), 1e-8, None)
+        onf = xp.where(on, 1.0 + zero, zero)
+        nbar = (-(weights[2] / N) * xp.sign(cs) * onf)[:, None] * (normals / (mn * nn)[:, None] - (cs / (nn * nn))[:, None] * n)
+        Hbar = 0.0 * H
+        for jj in range(2):
+            vj = V[..., jj]
+            coef = (vj * nbar).sum(-1) / (lam[..., 2] - lam[..., jj])
+            Hbar = Hbar + (0.5 * coef)[:, None, None] * (vj[:, :, None] * n[:, None, :] + n[:, :, None] * vj[:, None, :])
+        cot["nbar"], cot["Hbar"] = nbar, Hbar
     else:
         out["hessian_constraint"] = 0.0 * out["sdf_on_surf"]          # torch.Tensor([0])  :147
     if weights[3] != 0:
@@ -265,6 +278,78 @@ def param_grad(params, x, cache, rev, ybar, gbar, w0=30.0, xp=np):
     return list(zip(dW, db)), trace
 
 
+def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, xp=np):
+    """Full SURVEY.md Appendix A.5: d(loss)/d(params) when the loss also depends on the Hessian
+    (cotangent Hbar (N,3,3) on H[n,i,k] = d(df/dx_i)/dx_k), i.e. `backward()` through
+    reference src/diff_operators.py:187-193 + torch.linalg.eigh (src/loss_functions.py:141-145).
+    `tang` is the second return value of `hessian()` (zd[k][l], ad[k][l])."""
+    L = len(params) - 1
+    s, c = cache["s"], cache["c"]
+    a = rev["a"]
+    dW = [0.0 * W for W, _ in params]
+    db = [0.0 * b for _, b in params]
+    zd, ad = tang["zd"], tang["ad"]
+    # forward tangents hdot_{l-1}^k (inputs of layer l) and reverse tangents' qdot_l^k
+    hd = [[None] * (L + 1) for _ in range(3)]
+    qd = [[None] * L for _ in range(3)]
+    cd = [[None] * L for _ in range(3)]
+    for k in range(3):
+        e = 0.0 * x
+        e[:, k] = 1.0
+        hd[k][0] = e
+        for l in range(L):
+            hd[k][l + 1] = w0 * c[l] * zd[k][l]
+            cd[k][l] = -w0 * s[l] * zd[k][l]
+            qd[k][l] = w0 * (cd[k][l] * a[l] + c[l] * ad[k][l])
+    # (i) adjoint of the reverse sweeps, forward in l
+    Ap = gbar if gbar is not None else 0.0 * x
+    Adp = [Hbar[:, :, k] for k in range(3)]
+    cbar_rev, sbar_rev, zdbar_rev = [None] * L, [None] * L, [[None] * L for _ in range(3)]
+    for l in range(L):
+        W = params[l][0]
+        Q = xp.matmul(Ap, W.T)
+        Qd = [xp.matmul(Adp[k], W.T) for k in range(3)]
+        dW[l] = dW[l] + xp.matmul(rev["q"][l].T, Ap)
+        for k in range(3):
+            dW[l] = dW[l] + xp.matmul(qd[k][l].T, Adp[k])
+        chat = [w0 * a[l] * Qd[k] for k in range(3)]
+        Anew = w0 * c[l] * Q
+        cb = w0 * a[l] * Q
+        sb = 0.0 * Q
+        for k in range(3):
+            Anew = Anew + w0 * cd[k][l] * Qd[k]
+            cb = cb + w0 * ad[k][l] * Qd[k]
+            sb = sb - w0 * zd[k][l] * chat[k]
+            zdbar_rev[k][l] = -w0 * s[l] * chat[k]
+        cbar_rev[l], sbar_rev[l] = cb, sb
+        Adp = [w0 * c[l] * Qd[k] for k in range(3)]
+        Ap = Anew
+    dW[L] = dW[L] + Ap.sum(0)[None, :]
+    # (ii) adjoint of the forward sweeps, backward in l
+    Wo = params[-1][0]
+    hbar = ybar[:, None] * Wo[0][None, :]
+    hdbar = [0.0 * hbar for _ in range(3)]
+    dW[L] = dW[L] + xp.matmul(ybar[None, :], s[L - 1])
+    db[L] = db[L] + ybar.sum()[None]
+    for l in range(L - 1, -1, -1):
+        W = params[l][0]
+        zdbar = [zdbar_rev[k][l] + w0 * c[l] * hdbar[k] for k in range(3)]
+        cb = cbar_rev[l]
+        for k in range(3):
+            cb = cb + w0 * zd[k][l] * hdbar[k]
+        sb = sbar_rev[l] + hbar
+        zbar = w0 * c[l] * sb - w0 * s[l] * cb
+        hprev = x if l == 0 else s[l - 1]
+        dW[l] = dW[l] + xp.matmul(zbar.T, hprev)
+        for k in range(3):
+            dW[l] = dW[l] + xp.matmul(zdbar[k].T, hd[k][l])
+        db[l] = db[l] + zbar.sum(0)
+        if l > 0:
+            hbar = xp.matmul(zbar, W)
+            hdbar = [xp.matmul(zdbar[k], W) for k in range(3)]
+    return list(zip(dW, db))
+
+
 # --------------------------------------------------------------------------
 # one-call conveniences used by the tests / cpu_baseline
 # --------------------------------------------------------------------------
@@ -279,17 +364,15 @@ def query(params, x, w0=30.0, want_grad=True, want_hess=False, xp=np):
 
 
 def loss_and_grad(mode, params, x, normals, sdf, weights, alpha=100.0, w0=30.0, xp=np, s2_stats=None):
-    """mode in {'s1','s2','siren'}.  Returns (terms dict, grads list, debug dict).
-    For mode 's1' with weights[2] != 0 only the TERMS include the Hessian constraint; its
-    parameter gradient needs `param_grad_hessian` (not part of this first slice)."""
+    """mode in {'s1','s2','siren'}.  Returns (terms dict, grads list, debug dict)."""
     y, cache = forward(params, x, w0, xp)
     g, rev = (None, None)
     if mode in ("s1", "siren"):
         g, rev = input_gradient(params, cache, w0, xp)
-    H = None
+    H = tang = None
     if mode == "s1":
         if weights[2] != 0:
-            H, _ = hessian(params, x, cache, rev, w0, xp)
+            H, tang = hessian(params, x, cache, rev, w0, xp)
         terms, cot = loss_s1_terms(y, g, H, normals, sdf, weights, alpha, xp)
     elif mode == "siren":
         terms, cot = loss_siren_terms(y, g, normals, sdf, weights, xp)
@@ -297,8 +380,12 @@ def loss_and_grad(mode, params, x, normals, sdf, weights, alpha=100.0, w0=30.0, 
         terms, cot = loss_s2_terms(y, sdf, weights, xp, s2_stats)
     else:
         raise ValueError(mode)
-    grads, trace = param_grad(params, x, cache, rev, cot["ybar"], cot.get("gbar"), w0, xp)
-    dbg = {"y": y, "g": g, "H": H, "cache": cache, "rev": rev, "cot": cot, "trace": trace}
+    if mode == "s1" and weights[2] != 0:
+        grads = param_grad_hessian(params, x, cache, rev, tang, cot["ybar"], cot.get("gbar"), cot["Hbar"], w0, xp)
+        trace = None
+    else:
+        grads, trace = param_grad(params, x, cache, rev, cot["ybar"], cot.get("gbar"), w0, xp)
+    dbg = {"y": y, "g": g, "H": H, "tang": tang, "cache": cache, "rev": rev, "cot": cot, "trace": trace}
     return terms, grads, dbg
 
 

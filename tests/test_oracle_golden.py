@@ -42,7 +42,8 @@ def test_g1_fields_fp64(g1):
     assert rel(H, g1["f64_H"]) < 1e-12
 
 
-@pytest.mark.parametrize("case,mode,w", [("s1eik", "s1", W_S1EIK), ("s2", "s2", W_S2), ("siren", "siren", W_SIREN)])
+@pytest.mark.parametrize("case,mode,w", [("s1eik", "s1", W_S1EIK), ("s1full", "s1", W_S1FULL), ("s2", "s2", W_S2),
+                                         ("siren", "siren", W_SIREN)])
 def test_g1_loss_and_param_grads_fp64(g1, case, mode, w):
     hid = list(g1["hidden"])
     P = synth.siren_params(hid, seed=int(g1["param_seed"]), dtype=np.float64)
@@ -89,10 +90,11 @@ def test_g2_8x256_fields_and_grads(g2):
     assert rel(g, g2["f64_g"]) < 1e-12
     assert rel(H, g2["f64_H"]) < 1e-11
     sample = g2["sample"]
-    for case, mode, w in (("s1eik", "s1", W_S1EIK), ("s2", "s2", W_S2), ("siren", "siren", W_SIREN)):
+    for case, mode, w in (("s1eik", "s1", W_S1EIK), ("s1full", "s1", W_S1FULL), ("s2", "s2", W_S2),
+                          ("siren", "siren", W_SIREN)):
         terms, grads, _ = O.loss_and_grad(mode, P, x, nrm, sdf, w, 100.0)
         got = np.array([float(v) for v in terms.values()])
-        assert rel(got, g2[f"f64_{case}_terms"]) < 1e-11, case
+        assert rel(got, g2[f"f64_{case}_terms"]) < 1e-10, case
         fg = flat(grads)
         assert rel(fg[sample], g2[f"f64_{case}_dtheta_sample"]) < 1e-10, case
         nrm_ref = g2[f"f64_{case}_dtheta_norm"]
