@@ -15,8 +15,7 @@ _ERRORS = {
     -1: "DUDF_E_BADCFG: unsupported network (equal hidden widths in {32,64,128,256}, n_in=3, n_out=1)",
     -2: "DUDF_E_WORKSPACE: workspace too small or misaligned",
     -3: "DUDF_E_BADMODE",
-    -4: "DUDF_E_UNSUPPORTED: this loss configuration has no HIP path yet (loss_s1 with a non-zero "
-        "Hessian weight); there is deliberately no CPU fallback",
+    -4: "DUDF_E_UNSUPPORTED: this configuration has no HIP path; there is deliberately no CPU fallback",
 }
 
 
@@ -39,13 +38,16 @@ SYMBOLS = {
     "dudf_version": (ctypes.c_char_p, []),
     "dudf_theta_count": (ctypes.c_int64, [_CFG]),
     "dudf_workspace_bytes": (ctypes.c_size_t, [_CFG, ctypes.c_int64]),
+    "dudf_workspace_bytes_hess": (ctypes.c_size_t, [_CFG, ctypes.c_int64, ctypes.c_int64]),
     "dudf_query": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_query_hessian": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_loss_forward": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64,
-                                         _DBL, ctypes.c_double, _P, _P, ctypes.c_size_t, _P]),
+                                         ctypes.c_int64, _DBL, ctypes.c_double, _P, _P, ctypes.c_size_t, _P]),
     "dudf_s2_forward_stats": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int64, _P, _P, ctypes.c_size_t, _P]),
     "dudf_s2_terms": (ctypes.c_int, [_P, _DBL, _P, _P]),
     "dudf_loss_backward": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64,
-                                          _DBL, ctypes.c_double, _P, _P, _P, ctypes.c_int, _P, ctypes.c_size_t, _P]),
+                                          ctypes.c_int64, _DBL, ctypes.c_double, _P, _P, _P, ctypes.c_int, _P,
+                                          ctypes.c_size_t, _P]),
     "dudf_fields_forward": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_fields_backward": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int, _P,
                                             ctypes.c_size_t, _P]),
@@ -53,8 +55,8 @@ SYMBOLS = {
                                       ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_double, _P]),
     "dudf_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "dudf_profile_dump": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
-    "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P,
-                                             ctypes.c_size_t, _P]),
+    "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int64, _P, _P, ctypes.c_size_t, _P]),
 }
 
 

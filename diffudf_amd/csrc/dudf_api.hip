@@ -39,86 +39,143 @@ int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
     return 0;
 }
 
-SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, const float* x, float* ws) {
+SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     SweepArgs a;
     a.theta = theta; a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt;
-    a.x = x; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
-    a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R; a.E = ws + lo.ws_E; a.A = ws + lo.ws_A;
-    a.Z = ws + lo.ws_Z;
-    a.n = lo.n; a.np = lo.np; a.stash_layer = lo.stash_layer;
+    a.x4 = ws + lo.ws_x4; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
+    a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.ZS = ws + lo.ws_ZS; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R;
+    a.E = ws + lo.ws_E; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z;
+    a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.off_wo = lo.off_wo; a.off_bo = lo.off_bo;
     a.L = lo.L; a.w0 = lo.w0;
     a.store_s = 0; a.store_c = 0; a.train = 0; a.have_e = 1;
+    a.tile0 = 0; a.ntiles = 0; a.hess = 0;
     return a;
+}
+
+// one sweep over both column ranges: Hessian quads first, then the plain columns
+int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
+    int rc = 0;
+    if (lo.ncol_h > 0) {
+        a.tile0 = 0; a.ntiles = (int)(lo.ncol_h / DUDF_TILE_PTS); a.hess = 1;
+        if ((rc = dudf_launch_sweep(base + 4, lo.H, a, st))) return rc;
+    }
+    if (lo.ncol_n > 0) {
+        a.tile0 = (int)(lo.ncol_h / DUDF_TILE_PTS); a.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); a.hess = 0;
+        if ((rc = dudf_launch_sweep(base, lo.H, a, st))) return rc;
+    }
+    return 0;
+}
+
+struct Ctx {
+    DudfLayout lo;
+    hipStream_t st;
+    float* ws;
+};
+
+int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, size_t bytes, void* stream, Ctx* c) {
+    int rc = dudf_make_layout(cfg, n, n_h, &c->lo);
+    if (rc) return rc;
+    if ((rc = check_ws(c->lo, workspace, bytes))) return rc;
+    c->st = reinterpret_cast<hipStream_t>(stream);
+    c->ws = reinterpret_cast<float*>(workspace);
+    return 0;
+}
+
+// pack + x4 + forward (+ reverse) sweeps with the given stash flags
+int forward_common(Ctx& c, const float* theta, const float* x, int store_s, int store_c, int train, bool reverse) {
+    int rc;
+    if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
+    if ((rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
+    SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
+    a.store_s = store_s; a.store_c = store_c; a.train = train;
+    if ((rc = run_sweep(SWEEP_FWD, c.lo, a, c.st))) return rc;
+    if (reverse && (rc = run_sweep(SWEEP_REV, c.lo, a, c.st))) return rc;
+    return 0;
+}
+
+int backward_common(Ctx& c, const float* theta, int have_g, float* dtheta, int accumulate) {
+    int rc;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)c.lo.n_theta * sizeof(float), c.st);
+        if (e != hipSuccess) return (int)e;
+    }
+    SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
+    a.train = 1;
+    if (have_g) {
+        if ((rc = run_sweep(SWEEP_ADJ_FWD, c.lo, a, c.st))) return rc;
+    } else {
+        a.have_e = 0;                                   // no df/dx terms: e_l == 0 in the reverse adjoint sweep
+    }
+    if ((rc = run_sweep(SWEEP_ADJ_REV, c.lo, a, c.st))) return rc;
+    return dudf_launch_wgrad(c.lo, c.ws, dtheta, have_g, c.st);
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* dudf_version(void) { return "dudf_hip 0.1 (gfx950, fp32 MFMA 16x16x4 sweeps + 32x32x2 wgrad)"; }
+const char* dudf_version(void) {
+    return "dudf_hip 0.2 (gfx950, fp32 MFMA 16x16x4 sweeps incl. Hessian quads + 32x32x2 wgrad)";
+}
 
 int64_t dudf_theta_count(const dudf_net_cfg* cfg) {
     DudfLayout lo;
-    if (dudf_make_layout(cfg, 1, &lo)) return -1;
+    if (dudf_make_layout(cfg, 1, 0, &lo)) return -1;
     return lo.n_theta;
 }
 
 size_t dudf_workspace_bytes(const dudf_net_cfg* cfg, int64_t n) {
     DudfLayout lo;
-    if (dudf_make_layout(cfg, n, &lo)) return 0;
+    if (dudf_make_layout(cfg, n, 0, &lo)) return 0;
+    return lo.total_bytes;
+}
+
+size_t dudf_workspace_bytes_hess(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess) {
+    DudfLayout lo;
+    if (dudf_make_layout(cfg, n, n_hess, &lo)) return 0;
     return lo.total_bytes;
 }
 
 int dudf_query(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f, float* out_g,
                void* workspace, size_t workspace_bytes, void* stream) {
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n, &lo);
+    Ctx c;
+    int rc = open_ctx(cfg, n, 0, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
     if (n <= 0) return 0;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    if ((rc = dudf_launch_pack(lo, theta, ws, st))) return rc;
-    SweepArgs a = make_sweep_args(lo, theta, x, ws);
-    a.store_c = out_g ? 1 : 0;
-    if ((rc = dudf_launch_sweep(SWEEP_FWD, lo.H, a, st))) return rc;
-    if (out_g && (rc = dudf_launch_sweep(SWEEP_REV, lo.H, a, st))) return rc;
-    return dudf_launch_copy_out(lo, ws, out_f, out_g, st);
+    if ((rc = forward_common(c, theta, x, 0, out_g ? 1 : 0, 0, out_g != nullptr))) return rc;
+    return dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, nullptr, c.st);
+}
+
+int dudf_query_hessian(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f,
+                       float* out_g, float* out_h, void* workspace, size_t workspace_bytes, void* stream) {
+    Ctx c;
+    int rc = open_ctx(cfg, n, n, workspace, workspace_bytes, stream, &c);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if ((rc = forward_common(c, theta, x, 0, 1, 0, true))) return rc;
+    return dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, out_h, c.st);
 }
 
 int dudf_loss_forward(const dudf_net_cfg* cfg, int mode, const float* theta, const float* x, const float* normals,
-                      const float* sdf, int64_t n_local, int64_t n_global, const double* weights, double alpha,
-                      float* out_terms, void* workspace, size_t workspace_bytes, void* stream) {
+                      const float* sdf, int64_t n_local, int64_t n_global, int64_t n_hess, const double* weights,
+                      double alpha, float* out_terms, void* workspace, size_t workspace_bytes, void* stream) {
     if (mode != DUDF_LOSS_S1 && mode != DUDF_LOSS_SIREN) return DUDF_E_BADMODE;
-    if (mode == DUDF_LOSS_S1 && weights[2] != 0.0) return DUDF_E_UNSUPPORTED;   // Hessian term: not built yet
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n_local, &lo);
+    if (n_hess != 0 && !(mode == DUDF_LOSS_S1 && weights[2] != 0.0)) return DUDF_E_BADMODE;
+    Ctx c;
+    int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    if ((rc = dudf_launch_pack(lo, theta, ws, st))) return rc;
-    SweepArgs a = make_sweep_args(lo, theta, x, ws);
-    a.store_s = 1; a.store_c = 1; a.train = 1;
-    if ((rc = dudf_launch_sweep(SWEEP_FWD, lo.H, a, st))) return rc;
-    if ((rc = dudf_launch_sweep(SWEEP_REV, lo.H, a, st))) return rc;
-    return dudf_launch_loss_fwd(lo, mode, normals, sdf, n_global, weights, alpha, ws, out_terms, st);
+    if ((rc = forward_common(c, theta, x, 1, 1, 1, true))) return rc;
+    return dudf_launch_loss_fwd(c.lo, mode, normals, sdf, n_global, weights, alpha, c.ws, out_terms, c.st);
 }
 
 int dudf_s2_forward_stats(const dudf_net_cfg* cfg, const float* theta, const float* x, const float* sdf,
                           int64_t n_local, double* stats, void* workspace, size_t workspace_bytes, void* stream) {
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n_local, &lo);
+    Ctx c;
+    int rc = open_ctx(cfg, n_local, 0, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    if ((rc = dudf_launch_pack(lo, theta, ws, st))) return rc;
-    SweepArgs a = make_sweep_args(lo, theta, x, ws);
-    a.store_s = 1; a.store_c = 1; a.train = 1;
-    if ((rc = dudf_launch_sweep(SWEEP_FWD, lo.H, a, st))) return rc;
-    return dudf_launch_s2_stats(lo, sdf, ws, stats, st);
+    if ((rc = forward_common(c, theta, x, 1, 1, 1, false))) return rc;
+    return dudf_launch_s2_stats(c.lo, sdf, c.ws, stats, c.st);
 }
 
 int dudf_s2_terms(const double* stats, const double* weights, float* out_terms, void* stream) {
@@ -126,75 +183,39 @@ int dudf_s2_terms(const double* stats, const double* weights, float* out_terms, 
 }
 
 int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta, const float* x, const float* normals,
-                       const float* sdf, int64_t n_local, int64_t n_global, const double* weights, double alpha,
-                       const float* cot, const double* stats, float* dtheta, int accumulate, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       const float* sdf, int64_t n_local, int64_t n_global, int64_t n_hess, const double* weights,
+                       double alpha, const float* cot, const double* stats, float* dtheta, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream) {
     if (mode != DUDF_LOSS_S1 && mode != DUDF_LOSS_SIREN && mode != DUDF_LOSS_S2) return DUDF_E_BADMODE;
-    if (mode == DUDF_LOSS_S1 && weights[2] != 0.0) return DUDF_E_UNSUPPORTED;
     if (mode == DUDF_LOSS_S2 && !stats) return DUDF_E_BADMODE;
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n_local, &lo);
+    if (n_hess != 0 && !(mode == DUDF_LOSS_S1 && weights[2] != 0.0)) return DUDF_E_BADMODE;
+    Ctx c;
+    int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    const int have_g = (mode != DUDF_LOSS_S2);
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)lo.n_theta * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if ((rc = dudf_launch_loss_bwd(lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, ws, st))) return rc;
-    SweepArgs a = make_sweep_args(lo, theta, x, ws);
-    a.train = 1;
-    if (have_g) {
-        if ((rc = dudf_launch_sweep(SWEEP_ADJ_FWD, lo.H, a, st))) return rc;
-    } else {
-        a.have_e = 0;                                   // no df/dx terms: e_l == 0 in the reverse adjoint sweep
-    }
-    if ((rc = dudf_launch_sweep(SWEEP_ADJ_REV, lo.H, a, st))) return rc;
-    return dudf_launch_wgrad(lo, x, ws, dtheta, have_g, st);
+    (void)x;
+    if ((rc = dudf_launch_loss_bwd(c.lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, c.ws, c.st)))
+        return rc;
+    return backward_common(c, theta, mode != DUDF_LOSS_S2, dtheta, accumulate);
 }
 
 int dudf_fields_forward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f,
                         float* out_g, void* workspace, size_t workspace_bytes, void* stream) {
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n, &lo);
+    Ctx c;
+    int rc = open_ctx(cfg, n, 0, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    if ((rc = dudf_launch_pack(lo, theta, ws, st))) return rc;
-    SweepArgs a = make_sweep_args(lo, theta, x, ws);
-    a.store_s = 1; a.store_c = 1; a.train = 1;
-    if ((rc = dudf_launch_sweep(SWEEP_FWD, lo.H, a, st))) return rc;
-    if ((rc = dudf_launch_sweep(SWEEP_REV, lo.H, a, st))) return rc;
-    return dudf_launch_copy_out(lo, ws, out_f, out_g, st);
+    if ((rc = forward_common(c, theta, x, 1, 1, 1, true))) return rc;
+    return dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, nullptr, c.st);
 }
 
 int dudf_fields_backward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, const float* ybar,
                          const float* gbar, float* dtheta, int accumulate, void* workspace, size_t workspace_bytes,
                          void* stream) {
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n, &lo);
+    Ctx c;
+    int rc = open_ctx(cfg, n, 0, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)lo.n_theta * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if ((rc = dudf_launch_copy_in(lo, ybar, gbar, ws, st))) return rc;
-    SweepArgs a = make_sweep_args(lo, theta, x, ws);
-    a.train = 1;
-    const int have_g = gbar != nullptr;
-    if (have_g) {
-        if ((rc = dudf_launch_sweep(SWEEP_ADJ_FWD, lo.H, a, st))) return rc;
-    } else {
-        a.have_e = 0;
-    }
-    if ((rc = dudf_launch_sweep(SWEEP_ADJ_REV, lo.H, a, st))) return rc;
-    return dudf_launch_wgrad(lo, x, ws, dtheta, have_g, st);
+    (void)x;
+    if ((rc = dudf_launch_copy_in(c.lo, ybar, gbar, c.ws, c.st))) return rc;
+    return backward_common(c, theta, gbar != nullptr, dtheta, accumulate);
 }
 
 int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
@@ -231,17 +252,16 @@ int dudf_profile_dump(char* buf, size_t buflen) {
     return 0;
 }
 
-int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t n, float* out, void* workspace,
-                          size_t workspace_bytes, void* stream) {
-    DudfLayout lo;
-    int rc = dudf_make_layout(cfg, n, &lo);
+int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int channel, int64_t n, int64_t n_hess,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    Ctx c;
+    int rc = open_ctx(cfg, n, n_hess, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = check_ws(lo, workspace, workspace_bytes))) return rc;
-    if (layer < 0 || layer >= lo.L) return DUDF_E_BADCFG;
-    float* ws = reinterpret_cast<float*>(workspace);
-    const int64_t offs[7] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R};
-    if (which < 0 || which > 6) return DUDF_E_BADMODE;
-    return dudf_launch_read_stash(lo, ws + offs[which], layer, out, reinterpret_cast<hipStream_t>(stream));
+    if (layer < 0 || layer >= c.lo.L || channel < 0 || channel > 3) return DUDF_E_BADCFG;
+    const DudfLayout& lo = c.lo;
+    const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
+    if (which < 0 || which > 7) return DUDF_E_BADMODE;
+    return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st);
 }
 
 }  // extern "C"

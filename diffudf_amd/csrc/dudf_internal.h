@@ -7,7 +7,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define DUDF_TILE_PTS 128          // points per workgroup pass of a sweep kernel (8 waves x 16)
+#define DUDF_TILE_PTS 64           // columns per workgroup pass of a sweep kernel (4 waves x 16)
 #define DUDF_NACC 16               // doubles in the reduction scratch
 
 // Everything is in units of floats unless it says bytes.
@@ -15,38 +15,57 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // theta (caller's flat parameters, reference state_dict order):
 //   [W_1 (H,3)] [b_1 (H)] { [W_l (H,H)] [b_l (H)] } l=2..L  [W_out (1,H)] [b_out (1)]
 //
+// COLUMNS.  The sweeps and the weight-gradient GEMM work on "columns" of the activation matrices.
+//   * a point on the plain path (value + df/dx) is ONE column;
+//   * a point on the Hessian path is FOUR adjacent columns (a quad): channel 0 = the value path, channels 1..3 =
+//     the tangents d/dx_k of every forward and reverse quantity (forward-over-reverse).  The
+//     matmuls are linear, so tangents are just more columns of the same MFMAs; only the elementwise tails couple
+//     the four lanes of a quad (DPP quad broadcasts / sums).
+//   column ranges: [0, ncol_h) Hessian quads of the first n_h points, [ncol_h, ncol_h + ncol_n) plain columns of
+//   the remaining n - n_h points; both padded to whole 64-column tiles with zero columns.
+//
 // workspace:
 //   w1b    [H][4]      = [W_1 | b_1]        A-operand of the first layer (bias folded in as k=3)
 //   w1t16  [16][H]     rows 0..2 = W_1^T, rest 0: A-operand of the last reverse step (df/dx)
 //   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps
-//   y [np], g [np][4], ybar [np], gbar [np][4]
-//   seven stash arrays (s, c, q, r, e, A, zbar), each [L][H/4][np][4]:  element (layer li, feature f, point p) lives at
+//   per column: x4 [np][4] = layer-1 B operand (x,1 | e_k,0), y [np], g [np][4] (a_0 rows), ybar [np], gbar [np][4]
+//   stash arrays, each [L][H/4][np][4]:  element (layer li, feature f, column p) lives at
 //       ((li*(H/4) + f/4)*np + p)*4 + f%4
-//   i.e. "feature-quad major, point minor": the 16x16x4 MFMA accumulator of a wave (feature rows
-//   4q..4q+3 of a tile in its 4 registers, point = lane&15) is one aligned 16-byte store per lane,
-//   and the weight-gradient GEMM reads whole 16-byte [point][4 features] granules.
+//   i.e. "feature-quad major, column minor": the 16x16x4 MFMA accumulator of a wave (feature rows
+//   4q..4q+3 of a tile in its 4 registers, column = lane&15) is one aligned 16-byte store per lane,
+//   and the weight-gradient GEMM reads whole 16-byte [column][4 features] granules.
+//     S  h_l   | hdot_l^k      (forward outputs: Y operand of wgrad)       C  cos(w0 z_l)
+//     ZS s_l   | zdot_l^k      (Hessian columns only)                      Q  q_l | qdot_l^k   (X operand of wgrad)
+//     R  r_l = w0^2 s_l a_l (plain)  |  a_l | adot_l^k (Hessian)          E  e_l (see dudf_sweep.hip)
+//     A  A_l   | Adot_l^k      (Y operand of wgrad)                        Z  zbar_l | zdotbar_l^k (X operand)
 //   acc: DUDF_NACC doubles of reduction scratch (loss sums, s2 statistics)
 struct DudfLayout {
     int H, L;
     float w0;
-    int64_t n, np;
+    int64_t n, n_h;          // points, and how many of them (the first n_h) take the Hessian path
+    int64_t ncol_h, ncol_n;  // padded column counts of the two ranges
+    int64_t np;              // ncol_h + ncol_n
     // theta
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
-    int64_t ws_w1b, ws_w1t16, ws_wt, ws_y, ws_g, ws_ybar, ws_gbar;
-    int64_t ws_S, ws_C, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
+    int64_t ws_w1b, ws_w1t16, ws_wt, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
+    int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array
     size_t total_bytes;
 };
 
-static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, DudfLayout* lo) {
+static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo) {
     if (!cfg || cfg->n_in != 3 || cfg->n_hidden_layers < 1) return DUDF_E_BADCFG;
     const int H = cfg->hidden, L = cfg->n_hidden_layers;
     if (!(H == 32 || H == 64 || H == 128 || H == 256)) return DUDF_E_BADCFG;
+    if (n < 0 || n_h < 0 || n_h > n) return DUDF_E_BADCFG;
     lo->H = H; lo->L = L; lo->w0 = cfg->w0;
-    lo->n = n;
-    lo->np = (n + DUDF_TILE_PTS - 1) / DUDF_TILE_PTS * DUDF_TILE_PTS;
-    if (lo->np == 0) lo->np = DUDF_TILE_PTS;
+    lo->n = n; lo->n_h = n_h;
+    auto pad = [](int64_t c) { return (c + DUDF_TILE_PTS - 1) / DUDF_TILE_PTS * DUDF_TILE_PTS; };
+    lo->ncol_h = pad(4 * n_h);
+    lo->ncol_n = pad(n - n_h);
+    lo->np = lo->ncol_h + lo->ncol_n;
+    if (lo->np == 0) { lo->ncol_n = DUDF_TILE_PTS; lo->np = DUDF_TILE_PTS; }
     lo->off_w1 = 0; lo->off_b1 = 3 * (int64_t)H;
     lo->off_hid = 4 * (int64_t)H; lo->hid_stride = (int64_t)H * H + H;
     lo->off_wo = lo->off_hid + (L - 1) * lo->hid_stride; lo->off_bo = lo->off_wo + H;
@@ -56,12 +75,14 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, DudfLayou
     lo->ws_w1b = take(4 * (int64_t)H);
     lo->ws_w1t16 = take(16 * (int64_t)H);
     lo->ws_wt = take((int64_t)(L - 1) * H * H);
+    lo->ws_x4 = take(4 * lo->np);
     lo->ws_y = take(lo->np); lo->ws_g = take(4 * lo->np);
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
     lo->stash_layer = (int64_t)H * lo->np;
     const int64_t stash = (int64_t)L * lo->stash_layer;
     lo->ws_S = take(stash); lo->ws_C = take(stash); lo->ws_Q = take(stash);
     lo->ws_R = take(stash); lo->ws_E = take(stash); lo->ws_A = take(stash); lo->ws_Z = take(stash);
+    lo->ws_ZS = n_h > 0 ? take(stash) : lo->ws_S;
     lo->ws_acc = take(2 * DUDF_NACC);
     lo->total_bytes = (size_t)o * sizeof(float);
     return 0;
@@ -70,22 +91,26 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, DudfLayou
 // ---- launchers implemented in the .hip translation units -------------------------------------
 struct SweepArgs {
     const float* theta; const float* w1b; const float* w1t16; const float* wt;
-    const float* x;           // (n,3)
+    const float* x4;          // [np][4]: layer-1 B operand per column
     float* y; float* g;       // [np], [np][4]
     const float* ybar; const float* gbar;
-    float *S, *C, *Q, *R, *E, *A, *Z;
-    int64_t n, np, stash_layer;
+    float *S, *C, *ZS, *Q, *R, *E, *A, *Z;
+    int64_t np, stash_layer;
+    int tile0, ntiles;             // column range of this launch, in 64-column tiles
+    int hess;                      // 1: the range holds Hessian quads
     int64_t off_hid, hid_stride, off_wo, off_bo;
     int L; float w0;
     int store_s, store_c, train;   // what the sweep has to leave behind
     int have_e;                    // reverse adjoint sweep: e_l was produced by SWEEP_ADJ_FWD
 };
 
-enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3 };
+enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,
+       SWEEP_FWD_H = 4, SWEEP_REV_H = 5, SWEEP_ADJ_FWD_H = 6, SWEEP_ADJ_REV_H = 7 };   // Hessian-quad variants
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
-int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dtheta, int have_g, hipStream_t st);
+int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st);
+int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStream_t st);
 int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, float* ws, float* out_terms, hipStream_t st);
 int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
@@ -95,9 +120,10 @@ int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, doub
 int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms, hipStream_t st);
 int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
                      double eps, int64_t step, double gscale, hipStream_t st);
-int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, float* out, hipStream_t st);
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st);
 int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st);
-int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, hipStream_t st);
+int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, float* out_h,
+                         hipStream_t st);
 
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,

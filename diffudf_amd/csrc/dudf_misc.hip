@@ -48,15 +48,19 @@ __device__ __forceinline__ void block_accumulate(double (&v)[NV], double* __rest
 }
 
 struct LossArgs {
-    const float *y, *g, *normals, *sdf;     // y [np], g [np][4], normals (n,3), sdf (n)
-    float *ybar, *gbar;
+    const float *y, *g, *normals, *sdf;     // y [np], g [np][4] per COLUMN; normals (n,3), sdf (n) per POINT
+    float *ybar, *gbar;                      // per column
     const float* cot;                        // device, 4 floats
     const double* stats;                     // device, 3 doubles (s2)
     double* acc;                             // device, >= 4 doubles
-    int64_t n, np;
+    int64_t n, n_h, ncol_h, np;
     float w[4];
     float alpha, inv_n;                      // 1 / n_global
 };
+
+__device__ __forceinline__ int64_t col_of(const LossArgs& a, int64_t p) {
+    return p < a.n_h ? 4 * p : a.ncol_h + (p - a.n_h);
+}
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
@@ -73,19 +77,111 @@ __device__ __forceinline__ void s1_point(float y, const f32x4 g, float u, float 
     t_g = fabsf(gn - tau);
 }
 
-// mode 0: loss_s1 (Hessian weight must be 0), mode 2: loss_siren (reference :82-104, :24-32)
+// Symmetric 3x3 eigen-decomposition of the LOWER triangle (as torch.linalg.eigh reads it, reference
+// src/loss_functions.py:142), cyclic Jacobi in fp64, eigenvalues ascending.  V[i][j] = component i of v_j.
+__device__ __forceinline__ void eigh3(const double (&Hm)[3][3], double (&lam)[3], double (&V)[3][3]) {
+    double A[3][3] = {{Hm[0][0], Hm[1][0], Hm[2][0]}, {Hm[1][0], Hm[1][1], Hm[2][1]}, {Hm[2][0], Hm[2][1], Hm[2][2]}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 10; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dia = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-34 * dia || off == 0.0) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+            const double apq = A[p][q];
+            if (apq == 0.0) continue;
+            const double th = (A[q][q] - A[p][p]) / (2.0 * apq);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            const int r = 3 - p - q;
+            const double app = A[p][p], aqq = A[q][q], arp = A[r][p], arq = A[r][q];
+            A[p][p] = app - t * apq; A[q][q] = aqq + t * apq; A[p][q] = A[q][p] = 0.0;
+            A[r][p] = A[p][r] = c * arp - sn * arq;
+            A[r][q] = A[q][r] = sn * arp + c * arq;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double vip = V[i][p], viq = V[i][q];
+                V[i][p] = c * vip - sn * viq;
+                V[i][q] = sn * vip + c * viq;
+            }
+        }
+    }
+    lam[0] = A[0][0]; lam[1] = A[1][1]; lam[2] = A[2][2];
+    auto swp = [&](int i, int j) {
+        if (lam[i] > lam[j]) {
+            const double t = lam[i]; lam[i] = lam[j]; lam[j] = t;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const double u = V[k][i]; V[k][i] = V[k][j]; V[k][j] = u; }
+        }
+    };
+    swp(0, 1); swp(1, 2); swp(0, 1);
+}
+
+// Hessian of a quad: H[i][k] = (adot_0^k)_i = g[(4p+1+k)*4 + i]
+__device__ __forceinline__ void load_hessian(const LossArgs& a, int64_t p, double (&Hm)[3][3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const f32x4 col = *reinterpret_cast<const f32x4*>(a.g + (4 * p + 1 + k) * 4);
+        Hm[0][k] = col[0]; Hm[1][k] = col[1]; Hm[2][k] = col[2];
+    }
+}
+
+// (1 - |cos(m, n)|) for the top eigenvector n, and (when wanted) the cotangent of H for an upstream factor k2
+// on that term (reference principal_curvature_alignment :45-53 + eigh backward)
+__device__ __forceinline__ float hess_term(const LossArgs& a, int64_t p, const float* m3, double k2, bool want_bar,
+                                           double (&Hb)[3][3]) {
+    double Hm[3][3], lam[3], V[3][3];
+    load_hessian(a, p, Hm);
+    eigh3(Hm, lam, V);
+    const double m[3] = {m3[0], m3[1], m3[2]};
+    const double n[3] = {V[0][2], V[1][2], V[2][2]};
+    const double mn = fmax(sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]), 1e-8);
+    const double nn = fmax(sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-8);
+    const double cs = (m[0] * n[0] + m[1] * n[1] + m[2] * n[2]) / (mn * nn);
+    if (want_bar) {
+        const double sg = (cs > 0) ? 1.0 : ((cs < 0) ? -1.0 : 0.0);
+        double nb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nb[i] = -k2 * sg * (m[i] / (mn * nn) - cs * n[i] / (nn * nn));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Hb[i][k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double vj[3] = {V[0][j], V[1][j], V[2][j]};
+            const double coef = 0.5 * (vj[0] * nb[0] + vj[1] * nb[1] + vj[2] * nb[2]) / (lam[2] - lam[j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Hb[i][k] += coef * (vj[i] * n[k] + n[i] * vj[k]);
+        }
+    }
+    return (float)(1.0 - fabs(cs));
+}
+
+// mode 0: loss_s1, mode 2: loss_siren (reference :82-104, :24-32)
 template <int MODE>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
     double v[4] = {0, 0, 0, 0};
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * blockDim.x) {
-        const float y = a.y[p];
-        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + p * 4);
+        const int64_t c = col_of(a, p);
+        const float y = a.y[c];
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + c * 4);
         const float u = a.sdf[p];
         if constexpr (MODE == DUDF_LOSS_S1) {
             float t_on, t_off, t_g, tdf, gn, tau;
             s1_point(y, g, u, a.alpha, t_on, t_off, t_g, tdf, gn, tau);
             v[0] += t_on; v[1] += t_off;
             if (a.w[3] != 0.f) v[3] += t_g;
+            if (a.w[2] != 0.f && p < a.n_h && u == 0.f) {
+                double Hb[3][3];
+                v[2] += hess_term(a, p, a.normals + p * 3, 0.0, false, Hb);
+            }
         } else {
             const bool on = (u == 0.f);
             const float ay = fabsf(y);
@@ -114,7 +210,9 @@ __global__ void loss_finalize_kernel(const double* acc, float* out, double w0, d
     }
 }
 
-// cotangents ybar (on y) and gbar (on df/dx) of  sum_i cot[i] * term_i   
+// cotangents ybar (on y) and gbar (on the a_0 rows: df/dx, and for Hessian quads the three Hessian columns) of
+// sum_i cot[i] * term_i   (SURVEY.md Appendix A.4).  One thread per UNIT = one plain column or one whole quad;
+// padded columns get zeros.
 template <int MODE>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
     const float c0 = a.cot[0], c1 = a.cot[1], c2 = (MODE == DUDF_LOSS_S2) ? 0.f : a.cot[2],
@@ -125,15 +223,23 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
         mu = a.stats[1] / cnt;
         sd = sqrt((a.stats[2] - cnt * mu * mu) / (cnt - 1.0));
     }
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.np; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nq = a.ncol_h / 4;                                   // quads (padded)
+    const int64_t units = nq + (a.np - a.ncol_h);
+    for (int64_t uidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; uidx < units;
+         uidx += (int64_t)gridDim.x * blockDim.x) {
+        const bool quad = uidx < nq;
+        const int64_t p = quad ? uidx : a.n_h + (uidx - nq);
+        const int64_t c = quad ? 4 * uidx : a.ncol_h + (uidx - nq);
+        const bool valid = quad ? (p < a.n_h) : (p < a.n);
         float yb = 0.f;
         f32x4 gb = {0, 0, 0, 0};
-        if (p < a.n) {
-            const float y = a.y[p];
+        double Hb[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (valid) {
+            const float y = a.y[c];
             const float u = a.sdf[p];
             const bool on = (u == 0.f);
             if constexpr (MODE == DUDF_LOSS_S1) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + p * 4);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + c * 4);
                 float t_on, t_off, t_g, tdf, gn, tau;
                 s1_point(y, g, u, a.alpha, t_on, t_off, t_g, tdf, gn, tau);
                 yb = on ? c0 * a.w[0] * a.inv_n * sgn(y) : -c1 * a.w[1] * a.inv_n * sgn(tdf - y);
@@ -141,8 +247,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
                     const float k = c3 * a.w[3] * a.inv_n * sgn(gn - tau) / gn;
                     gb = f32x4{k * g[0], k * g[1], k * g[2], 0.f};
                 }
+                if (quad && a.w[2] != 0.f && on)
+                    hess_term(a, p, a.normals + p * 3, (double)c2 * a.w[2] * a.inv_n, true, Hb);
             } else if constexpr (MODE == DUDF_LOSS_SIREN) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + p * 4);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + c * 4);
                 const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
                 yb = on ? c0 * a.w[0] * a.inv_n * sgn(y)
                         : -c1 * a.w[1] * a.inv_n * 100.f * sgn(y) * expf(-100.f * fabsf(y));
@@ -167,17 +275,24 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
                 }
             }
         }
-        a.ybar[p] = yb;
-        *reinterpret_cast<f32x4*>(a.gbar + p * 4) = gb;
+        a.ybar[c] = yb;
+        *reinterpret_cast<f32x4*>(a.gbar + c * 4) = gb;
+        if (quad) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {                // cotangent of adot_0^k = column k of Hbar
+                a.ybar[c + 1 + k] = 0.f;
+                *reinterpret_cast<f32x4*>(a.gbar + (c + 1 + k) * 4) =
+                    f32x4{(float)Hb[0][k], (float)Hb[1][k], (float)Hb[2][k], 0.f};
+            }
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void s2_stats_kernel(const float* __restrict__ y, const float* __restrict__ sdf,
-                                                       int64_t n, double* __restrict__ stats) {
+__global__ __launch_bounds__(256) void s2_stats_kernel(LossArgs a, double* __restrict__ stats) {
     double v[3] = {0, 0, 0};
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        if (sdf[p] == 0.f) {
-            const double yy = y[p];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (a.sdf[p] == 0.f) {
+            const double yy = a.y[col_of(a, p)];
             v[0] += 1.0; v[1] += yy; v[2] += yy * yy;
         }
     }
@@ -190,6 +305,26 @@ __global__ void s2_terms_kernel(const double* stats, double w0, double w1, float
         const double var = (stats[2] - cnt * mu * mu) / (cnt - 1.0);
         out[0] = (float)(fabs(mu) * w0);
         out[1] = (float)(sqrt(var > 0 ? var : 0.0) * w1);
+    }
+}
+
+// x4: the layer-1 B operand of every column.  plain column: (x0,x1,x2,1) — the 1 multiplies the bias column of
+// [W_1|b_1]; Hessian quad: channel 0 the same, channel 1+k = (e_k, 0) (hdot_0^k = e_k, no bias); padding: zeros.
+__global__ __launch_bounds__(256) void make_x4_kernel(const float* __restrict__ x, float* __restrict__ x4, int64_t n,
+                                                      int64_t n_h, int64_t ncol_h, int64_t np) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < np; c += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = {0, 0, 0, 0};
+        if (c < ncol_h) {
+            const int64_t p = c >> 2; const int ch = (int)(c & 3);
+            if (p < n_h) {
+                if (ch == 0) v = f32x4{x[p * 3], x[p * 3 + 1], x[p * 3 + 2], 1.f};
+                else v[ch - 1] = 1.f;
+            }
+        } else {
+            const int64_t p = n_h + (c - ncol_h);
+            if (p < n) v = f32x4{x[p * 3], x[p * 3 + 1], x[p * 3 + 2], 1.f};
+        }
+        *reinterpret_cast<f32x4*>(x4 + c * 4) = v;
     }
 }
 
@@ -209,31 +344,45 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, co
 }
 
 __global__ __launch_bounds__(256) void read_stash_kernel(const float* __restrict__ src, float* __restrict__ out,
-                                                         int64_t n, int64_t np, int H) {
+                                                         int64_t n, int64_t n_h, int64_t ncol_h, int64_t np, int H,
+                                                         int channel) {
     const int64_t tot = n * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / H; const int f = (int)(i % H);
-        out[i] = src[((int64_t)(f >> 2) * np + p) * 4 + (f & 3)];
+        const int64_t c = p < n_h ? 4 * p + channel : ncol_h + (p - n_h);
+        out[i] = src[((int64_t)(f >> 2) * np + c) * 4 + (f & 3)];
     }
 }
 
+// out_f (n), out_g (n,3), out_h (n,3,3) [Hessian points first n_h only meaningful], any may be null
 __global__ __launch_bounds__(256) void copy_out_kernel(const float* __restrict__ y, const float* __restrict__ g,
-                                                       float* __restrict__ of, float* __restrict__ og, int64_t n) {
+                                                       float* __restrict__ of, float* __restrict__ og,
+                                                       float* __restrict__ oh, int64_t n, int64_t n_h, int64_t ncol_h) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        if (of) of[p] = y[p];
-        if (og) { og[p * 3] = g[p * 4]; og[p * 3 + 1] = g[p * 4 + 1]; og[p * 3 + 2] = g[p * 4 + 2]; }
+        const int64_t c = p < n_h ? 4 * p : ncol_h + (p - n_h);
+        if (of) of[p] = y[c];
+        if (og) { og[p * 3] = g[c * 4]; og[p * 3 + 1] = g[c * 4 + 1]; og[p * 3 + 2] = g[c * 4 + 2]; }
+        if (oh && p < n_h) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) oh[p * 9 + i * 3 + k] = g[(c + 1 + k) * 4 + i];
+        }
     }
 }
 
+// ybar (n) / gbar (n,3) given per POINT by the caller -> per column (tangent channels and padding zero)
 __global__ __launch_bounds__(256) void copy_in_kernel(const float* __restrict__ ybar, const float* __restrict__ gbar,
                                                       float* __restrict__ wy, float* __restrict__ wg, int64_t n,
-                                                      int64_t np) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
-        const bool in = p < n;
-        wy[p] = (in && ybar) ? ybar[p] : 0.f;
-        f32x4 g = {0, 0, 0, 0};
-        if (in && gbar) g = f32x4{gbar[p * 3], gbar[p * 3 + 1], gbar[p * 3 + 2], 0.f};
-        *reinterpret_cast<f32x4*>(wg + p * 4) = g;
+                                                      int64_t n_h, int64_t ncol_h, int64_t np) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < np; c += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = -1;
+        if (c < ncol_h) { if ((c & 3) == 0 && (c >> 2) < n_h) p = c >> 2; }
+        else if (n_h + (c - ncol_h) < n) p = n_h + (c - ncol_h);
+        wy[c] = (p >= 0 && ybar) ? ybar[p] : 0.f;
+        f32x4 gv = {0, 0, 0, 0};
+        if (p >= 0 && gbar) gv = f32x4{gbar[p * 3], gbar[p * 3 + 1], gbar[p * 3 + 2], 0.f};
+        *reinterpret_cast<f32x4*>(wg + c * 4) = gv;
     }
 }
 
@@ -250,7 +399,7 @@ LossArgs make_loss_args(const DudfLayout& lo, const float* normals, const float*
     a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.normals = normals; a.sdf = sdf;
     a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar; a.cot = nullptr; a.stats = nullptr;
     a.acc = reinterpret_cast<double*>(ws + lo.ws_acc);
-    a.n = lo.n; a.np = lo.np;
+    a.n = lo.n; a.n_h = lo.n_h; a.ncol_h = lo.ncol_h; a.np = lo.np;
     for (int i = 0; i < 4; ++i) a.w[i] = (float)w[i];
     a.alpha = (float)alpha; a.inv_n = (float)(1.0 / (double)n_global);
     return a;
@@ -299,7 +448,9 @@ int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, c
 int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, double* stats, hipStream_t st) {
     hipError_t e = hipMemsetAsync(stats, 0, 3 * sizeof(double), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(s2_stats_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, sdf, lo.n, stats);
+    const double w0[4] = {0, 0, 0, 0};
+    LossArgs a = make_loss_args(lo, nullptr, sdf, 1, w0, 0.0, ws);
+    hipLaunchKernelGGL(s2_stats_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, a, stats);
     return (int)hipGetLastError();
 }
 
@@ -317,21 +468,29 @@ int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n
     return (int)hipGetLastError();
 }
 
-int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, float* out, hipStream_t st) {
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st) {
     hipLaunchKernelGGL(read_stash_kernel, dim3(grid_for(lo.n * lo.H)), dim3(256), 0, st,
-                       src + (int64_t)layer * lo.stash_layer, out, lo.n, lo.np, lo.H);
+                       src + (int64_t)layer * lo.stash_layer, out, lo.n, lo.n_h, lo.ncol_h, lo.np, lo.H, channel);
     return (int)hipGetLastError();
 }
 
-int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, hipStream_t st) {
+int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, float* out_h,
+                         hipStream_t st) {
     hipLaunchKernelGGL(copy_out_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, ws + lo.ws_g, out_f,
-                       out_g, lo.n);
+                       out_g, out_h, lo.n, lo.n_h, lo.ncol_h);
     return (int)hipGetLastError();
 }
 
 int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st) {
     DudfProfScope prof(PROF_OTHER, st);
     hipLaunchKernelGGL(copy_in_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, ybar, gbar, ws + lo.ws_ybar,
-                       ws + lo.ws_gbar, lo.n, lo.np);
+                       ws + lo.ws_gbar, lo.n, lo.n_h, lo.ncol_h, lo.np);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(make_x4_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, x, ws + lo.ws_x4, lo.n, lo.n_h,
+                       lo.ncol_h, lo.np);
     return (int)hipGetLastError();
 }

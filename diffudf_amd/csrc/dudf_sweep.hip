@@ -83,23 +83,6 @@ __device__ __forceinline__ void stage_issue(const float* __restrict__ M, int r, 
     }
 }
 
-// The LDS-DMA pieces this wave issued have landed.  vmcnt counts every vector-memory operation of the wave in
-// issue order, and the asm statements pin that order: after the DMA pieces of a chunk come exactly
-// younger_ops<SW,FL>() compiler-issued operations (operand loads of the next tail + stash stores of the current
-// one), so waiting for "all but that many" retires the DMA while those stay in flight.
-// tests/test_isa_contract.py counts the instructions in the built code object and fails if this drifts.
-template <int SW, int FL>
-constexpr int younger_ops() {
-    return SW == SWEEP_FWD ? 2 + 2 * ((FL & 1) + ((FL >> 1) & 1))      // 2 bias loads + s/c stores of 2 tiles
-         : SW == SWEEP_REV ? ((FL & 1) ? 4 + 4 : 2)                     // c,s loads + q,r stores | c loads
-         : SW == SWEEP_ADJ_FWD ? 4 + 4                                  // c,r loads + A,e stores
-         : ((FL & 1) ? 4 + 2 : 2 + 2);                                  // c(,e) loads + zbar stores
-}
-template <int H, int N>
-__device__ __forceinline__ void dma_wait() {
-    if constexpr (Geo<H>::DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
-
 template <int H>
 __device__ __forceinline__ void stage_commit(float* buf, const f32x4 (&stg)[Geo<H>::NSTG], int tid) {
     using G = Geo<H>;
@@ -121,12 +104,34 @@ __device__ __forceinline__ void stage_commit(float* buf, const f32x4 (&stg)[Geo<
 #define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>((arr) + (ub) + (vo))
 #define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>((arr) + (ub) + (vo))
 
-// Elementwise tail of one 16-feature x 16-point tile.
+// ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
+__device__ __forceinline__ float quad_bcast0(float v) {          // value of the quad's lane 0 (the value channel)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x00, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {             // sum over the quad, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
+constexpr bool is_hess(int SW) { return SW >= 4; }
+constexpr int base_of(int SW) { return SW & 3; }
+
+// Elementwise tail of one 16-feature x 16-column tile.
 // FL (compile-time, so the tail stays one basic block that can be interleaved with MFMAs):
 //   SWEEP_FWD: bit0 = stash s_l, bit1 = stash c_l;  SWEEP_REV: bit0 = training (stash q_l, r_l);
 //   SWEEP_ADJ_REV: bit0 = e_l exists (df/dx terms present)
+//   Hessian variants: SWEEP_FWD_H / SWEEP_REV_H bit0 = training; the adjoint ones ignore FL.
+// Hessian quads (lane&3 = channel, 0 = value, 1+k = d/dx_k):
+//   FWD_H      z|zdot^k        -> h = s | hdot^k = w0 c zdot^k                      stash C = c, ZS = s|zdot^k, S = out
+//   REV_H      a|adot^k        -> q = w0 c a | qdot^k = w0(-w0 s zdot^k a + c adot^k)   stash Q = out, R = a|adot^k
+//   ADJ_FWD_H  Q|Qdot^k        -> A = w0 c Q + w0 sum_k cdot^k Qdot^k | Adot^k = w0 c Qdot^k          stash A = out,
+//              E = w0 c sbar_rev - w0 s cbar_rev | zdotbar_rev^k = -w0 s chat^k, chat^k = w0 a Qdot^k,
+//              cbar_rev = w0 a Q + w0 sum_k adot^k Qdot^k, sbar_rev = -w0 sum_k zdot^k chat^k
+//   ADJ_REV_H  hbar|hdotbar^k  -> zbar = E + w0 c hbar - w0^2 s sum_k zdot^k hdotbar^k | zdotbar^k = E + w0 c hdotbar^k
 template <int SW, int FL>
-__device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, int64_t ub, unsigned vo) {
+__device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
+                                          unsigned vo, bool isv) {
     f32x4 out;
     if constexpr (SW == SWEEP_FWD) {
         f32x4 s, c;
@@ -149,54 +154,135 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
         *DUDF_AT(a.A, ub, vo) = out;
         *DUDF_AT(a.E, ub, vo) = o2 * acc;            // e_l = r_l Q_l
-    } else {                                         // acc = hbar_l, o1 = c_l, o2 = e_l
+    } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
+        *DUDF_AT(a.Z, ub, vo) = out;
+    } else if constexpr (SW == SWEEP_FWD_H) {
+        f32x4 c, zs;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float sv, cv;
+            dudf_sincos(a.w0 * quad_bcast0(acc[t]), &sv, &cv);
+            c[t] = cv;
+            zs[t] = isv ? sv : acc[t];
+            out[t] = isv ? sv : a.w0 * cv * acc[t];
+        }
+        *DUDF_AT(a.C, ub, vo) = c;
+        *DUDF_AT(a.ZS, ub, vo) = zs;
+        if constexpr (FL & 1) *DUDF_AT(a.S, ub, vo) = out;
+    } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float sv = quad_bcast0(o2[t]), a0 = quad_bcast0(acc[t]);
+            out[t] = isv ? a.w0 * o1[t] * acc[t] : a.w0 * (o1[t] * acc[t] - a.w0 * sv * o2[t] * a0);
+        }
+        if constexpr (FL & 1) {
+            *DUDF_AT(a.Q, ub, vo) = out;
+            *DUDF_AT(a.R, ub, vo) = acc;
+        }
+    } else if constexpr (SW == SWEEP_ADJ_FWD_H) {    // o1 = c, o2 = s|zdot^k, o3 = a|adot^k
+        f32x4 e;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float sv = quad_bcast0(o2[t]), a0 = quad_bcast0(o3[t]);
+            const float cdot = -a.w0 * sv * o2[t];
+            const float chat = a.w0 * a0 * acc[t];
+            const float s1 = quad_sum(isv ? 0.f : cdot * acc[t]);
+            const float s2 = quad_sum(isv ? 0.f : o3[t] * acc[t]);
+            const float s3 = quad_sum(isv ? 0.f : o2[t] * chat);
+            const float cbar = a.w0 * (o3[t] * acc[t] + s2);
+            const float sbar = -a.w0 * s3;
+            out[t] = a.w0 * (o1[t] * acc[t] + (isv ? s1 : 0.f));
+            e[t] = isv ? a.w0 * (o1[t] * sbar - sv * cbar) : -a.w0 * sv * chat;
+        }
+        *DUDF_AT(a.A, ub, vo) = out;
+        *DUDF_AT(a.E, ub, vo) = e;
+    } else {                                         // SWEEP_ADJ_REV_H: o1 = c, o2 = s|zdot^k, o3 = E
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float sv = quad_bcast0(o2[t]);
+            const float st = quad_sum(isv ? 0.f : o2[t] * acc[t]);
+            out[t] = o3[t] + a.w0 * o1[t] * acc[t] - (isv ? a.w0 * a.w0 * sv * st : 0.f);
+        }
         *DUDF_AT(a.Z, ub, vo) = out;
     }
     return out;
 }
 
 template <int SW, int FL>
-__device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, unsigned vo, f32x4& o1, f32x4& o2) {
+__device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, unsigned vo, f32x4& o1, f32x4& o2,
+                                               f32x4& o3) {
+    o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
     if constexpr (SW == SWEEP_REV) {
         o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = (FL & 1) ? *DUDF_CAT(a.S, ub, vo) : f32x4{0, 0, 0, 0};
+        if constexpr (FL & 1) o2 = *DUDF_CAT(a.S, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
         o1 = *DUDF_CAT(a.C, ub, vo);
         o2 = *DUDF_CAT(a.R, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
         o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = (FL & 1) ? *DUDF_CAT(a.E, ub, vo) : f32x4{0, 0, 0, 0};   // no df/dx terms (loss_s2): e_l == 0
-    } else {
-        o1 = f32x4{0, 0, 0, 0}; o2 = o1;
+        if constexpr (FL & 1) o2 = *DUDF_CAT(a.E, ub, vo);            // no df/dx terms (loss_s2): e_l == 0
+    } else if constexpr (SW == SWEEP_REV_H) {
+        o1 = *DUDF_CAT(a.C, ub, vo);
+        o2 = *DUDF_CAT(a.ZS, ub, vo);
+    } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
+        o1 = *DUDF_CAT(a.C, ub, vo);
+        o2 = *DUDF_CAT(a.ZS, ub, vo);
+        o3 = *DUDF_CAT(a.R, ub, vo);
+    } else if constexpr (SW == SWEEP_ADJ_REV_H) {
+        o1 = *DUDF_CAT(a.C, ub, vo);
+        o2 = *DUDF_CAT(a.ZS, ub, vo);
+        o3 = *DUDF_CAT(a.E, ub, vo);
     }
+}
+
+// The LDS-DMA pieces this wave issued have landed.  vmcnt counts every vector-memory operation of the wave in
+// issue order, and the asm statements pin that order: after the DMA pieces of a chunk come exactly
+// younger_ops<SW,FL>() compiler-issued operations (operand loads of the next tail + stash stores of the current
+// one), so waiting for "all but that many" retires the DMA while those stay in flight.
+// tests/test_isa_contract.py counts the instructions in the built code object and fails if this drifts.
+template <int SW, int FL>
+constexpr int younger_ops() {
+    return SW == SWEEP_FWD ? 2 + 2 * ((FL & 1) + ((FL >> 1) & 1))      // 2 bias loads + s/c stores of 2 tiles
+         : SW == SWEEP_REV ? ((FL & 1) ? 4 + 4 : 2)                     // c,s loads + q,r stores | c loads
+         : SW == SWEEP_ADJ_FWD ? 4 + 4                                  // c,r loads + A,e stores
+         : SW == SWEEP_ADJ_REV ? ((FL & 1) ? 4 + 2 : 2 + 2)             // c(,e) loads + zbar stores
+         : SW == SWEEP_FWD_H ? 2 + 2 * (2 + (FL & 1))                   // bias + C,ZS(,S) stores
+         : SW == SWEEP_REV_H ? 4 + ((FL & 1) ? 4 : 0)                   // c,zs loads + Q,R stores
+         : SW == SWEEP_ADJ_FWD_H ? 6 + 4                                // c,zs,aa loads + A,E stores
+         : 6 + 2;                                                       // c,zs,E loads + Z stores
+}
+template <int H, int N>
+__device__ __forceinline__ void dma_wait() {
+    if constexpr (Geo<H>::DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
 // Two finished accumulator tiles whose elementwise tail has not run yet.  The tail of chunk r-1 is executed in
 // the middle of chunk r's MFMA stream (same basic block), so sin/cos, stash traffic and MFMAs overlap inside
 // one wave instead of serialising at every chunk barrier.
 struct Pending {
-    f32x4 acc0, acc1, o1a, o2a, o1b, o2b;
+    f32x4 acc0, acc1, o1a, o2a, o3a, o1b, o2b, o3b;
     int64_t ub0, ub1;
 };
 
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
     using G = Geo<H>;
+    constexpr int BS = base_of(SW);
+    constexpr bool HS = is_hess(SW);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int ntiles = (int)(a.np / TILE);
+    const bool isv = !HS || (lane & 3) == 0;           // value channel (always, on the plain path)
     const int nhid = a.L - 1;                          // hidden x hidden layers
-    constexpr bool kFwdDir = (SW == SWEEP_FWD || SW == SWEEP_ADJ_FWD);
+    constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
 
     f32x4 in[G::NT], nxt[G::NT];
     f32x4 stg[G::NSTG];
     unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t p = (int64_t)tile * TILE + wave * 16 + li;
-        const bool valid = p < a.n;
+    for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x) {
+        const int64_t p = (int64_t)tile * TILE + wave * 16 + li;        // this lane's column
         // j-th hidden matrix this sweep multiplies by, and the 0-based layer index its output belongs to
         auto matrix = [&](int j) -> const float* {
             return kFwdDir ? a.theta + a.off_hid + (int64_t)j * a.hid_stride
@@ -216,26 +302,27 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
         Pending pend;
         {
             float b = 0.f, yb = 1.f;
-            if constexpr (SW == SWEEP_FWD) b = (q < 3) ? (valid ? a.x[p * 3 + q] : 0.f) : 1.f;   // k=3 carries the bias
-            if constexpr (SW == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;            // A_0 = gbar
-            if constexpr (SW == SWEEP_ADJ_REV) yb = a.ybar[p];
+            if constexpr (BS == SWEEP_FWD) b = a.x4[p * 4 + q];                       // (x,1) | (e_k,0): k=3 carries the bias
+            if constexpr (BS == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f; // A_0 = gbar | Hbar columns
+            if constexpr (BS == SWEEP_ADJ_REV) yb = a.ybar[p];
+            if constexpr (SW == SWEEP_REV_H) yb = isv ? 1.f : 0.f;                    // adot_L^k = 0
             const int l0 = kFwdDir ? 0 : a.L - 1;
 #pragma unroll
             for (int T = 0; T < G::NT; ++T) {
                 const int64_t ub = stash_base(l0, T);
-                f32x4 o1, o2, acc;
-                epilogue_loads<SW, FL>(a, ub, vo, o1, o2);
+                f32x4 o1, o2, o3, acc;
+                epilogue_loads<SW, FL>(a, ub, vo, o1, o2, o3);
                 if constexpr (kFwdDir) {
                     acc = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
                 } else {
                     acc = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
                 }
                 if (T < G::NT - 2) {
-                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, ub, vo);
+                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, o3, ub, vo, isv);
                 } else if (T == G::NT - 2) {
-                    pend.acc0 = acc; pend.o1a = o1; pend.o2a = o2; pend.ub0 = ub;
+                    pend.acc0 = acc; pend.o1a = o1; pend.o2a = o2; pend.o3a = o3; pend.ub0 = ub;
                 } else {
-                    pend.acc1 = acc; pend.o1b = o1; pend.o2b = o2; pend.ub1 = ub;
+                    pend.acc1 = acc; pend.o1b = o1; pend.o2b = o2; pend.o3b = o3; pend.ub1 = ub;
                 }
             }
         }
@@ -247,7 +334,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
         //   -> DMA issue for the next chunk -> operand/bias loads for the next tail -> remaining MFMAs
         //   -> dma_wait + barrier.
         f32x4 bias0 = {0, 0, 0, 0}, bias1 = {0, 0, 0, 0};
-        if constexpr (SW == SWEEP_FWD) {
+        if constexpr (BS == SWEEP_FWD) {
             if (nhid > 0) {
                 const float* bias = matrix(0) + (size_t)H * H;
                 bias0 = *reinterpret_cast<const f32x4*>(bias + 4 * q);
@@ -268,20 +355,27 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
                 cur.ub0 = stash_base(lo, 2 * r); cur.ub1 = stash_base(lo, 2 * r + 1);
                 // the bias loads issued during the previous chunk have landed: make the compiler wait for them
                 // here, before this chunk's LDS-DMA goes in flight
-                if constexpr (SW == SWEEP_FWD) asm volatile("" : "+v"(bias0), "+v"(bias1));
-                cur.acc0 = bias0; cur.acc1 = bias1;
+                if constexpr (BS == SWEEP_FWD) asm volatile("" : "+v"(bias0), "+v"(bias1));
+                if constexpr (HS) {                      // z = W h + b only in the value channel
+                    cur.acc0 = isv ? bias0 : f32x4{0, 0, 0, 0};
+                    cur.acc1 = isv ? bias1 : f32x4{0, 0, 0, 0};
+                } else {
+                    cur.acc0 = bias0; cur.acc1 = bias1;
+                }
                 const float* bp = lds + (gc & 1) * G::BUF + li * G::LDW + 4 * q;
                 auto chunk_head = [&]() {
                     // operands of the previous chunk's tail have landed: the compiler puts its own vmcnt wait
                     // HERE, while no LDS-DMA of this chunk is in flight yet
-                    if constexpr (SW != SWEEP_FWD)
+                    if constexpr (BS != SWEEP_FWD)
                         asm volatile("" : "+v"(pend.o1a), "+v"(pend.o2a), "+v"(pend.o1b), "+v"(pend.o2b));
+                    if constexpr (SW == SWEEP_ADJ_FWD_H || SW == SWEEP_ADJ_REV_H)
+                        asm volatile("" : "+v"(pend.o3a), "+v"(pend.o3b));
                     float* nbuf = lds + ((gc + 1) & 1) * G::BUF;
                     if (r + 1 < G::NCH) stage_issue<H>(M, r + 1, nbuf, stg, tid);
                     else if (Mn) stage_issue<H>(Mn, 0, nbuf, stg, tid);
-                    epilogue_loads<SW, FL>(a, cur.ub0, vo, cur.o1a, cur.o2a);
-                    epilogue_loads<SW, FL>(a, cur.ub1, vo, cur.o1b, cur.o2b);
-                    if constexpr (SW == SWEEP_FWD) {
+                    epilogue_loads<SW, FL>(a, cur.ub0, vo, cur.o1a, cur.o2a, cur.o3a);
+                    epilogue_loads<SW, FL>(a, cur.ub1, vo, cur.o1b, cur.o2b, cur.o3b);
+                    if constexpr (BS == SWEEP_FWD) {
                         const float* bias = (r + 1 < G::NCH) ? M + (size_t)H * H + 32 * (r + 1)
                                                              : (Mn ? Mn + (size_t)H * H : M + (size_t)H * H);
                         bias0 = *reinterpret_cast<const f32x4*>(bias + 4 * q);
@@ -291,8 +385,8 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
                     // freely interleavable region
                     __builtin_amdgcn_sched_barrier(0);
                     // tail of the previous chunk's two tiles (the previous layer's last two when r == 0)
-                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.ub0, vo);
-                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.ub1, vo);
+                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv);
+                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv);
                     if (r == 0) { in[G::NT - 2] = e0; in[G::NT - 1] = e1; }
                     else { nxt[2 * r - 2] = e0; nxt[2 * r - 1] = e1; }
                 };
@@ -321,11 +415,11 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
             for (int T = 0; T < G::NT - 2; ++T) in[T] = nxt[T];
         }
         // flush the last pending pair
-        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.ub0, vo);
-        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.ub1, vo);
+        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv);
+        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv);
 
         // ------------------------------ tail ------------------------------
-        if constexpr (SW == SWEEP_FWD) {                // y = W_out s_L + b_out
+        if constexpr (BS == SWEEP_FWD) {                // y = W_out h_L + b_out (tangent channels: their own dot, unused)
             float part = 0.f;
 #pragma unroll
             for (int T = 0; T < G::NT; ++T) {
@@ -335,7 +429,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
             part += __shfl_xor(part, 16);               // the 4 lane quarters hold disjoint feature rows
             part += __shfl_xor(part, 32);
             if (q == 0) a.y[p] = part + a.theta[a.off_bo];
-        } else if constexpr (SW == SWEEP_REV) {         // df/dx = W_1^T q_1 (rows 0..2 of a 16-row tile)
+        } else if constexpr (BS == SWEEP_REV) {         // a_0 = W_1^T q_1 (rows 0..2 of a 16-row tile): df/dx | Hessian column
             f32x4 accg = {0, 0, 0, 0};
 #pragma unroll
             for (int T = 0; T < G::NT; ++T) {
@@ -352,7 +446,8 @@ template <int H>
 int launch_h(int which, const SweepArgs& a, hipStream_t st) {
     using G = Geo<H>;
     const size_t smem = 2 * G::BUF * sizeof(float);
-    const int ntiles = (int)(a.np / TILE);
+    const int ntiles = a.ntiles;
+    if (ntiles <= 0) return 0;
     int grid = ntiles < 512 ? ntiles : 512;            // two 4-wave workgroups per CU
     if (grid < 1) grid = 1;
     hipError_t e = hipSuccess;
@@ -381,6 +476,10 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
         case SWEEP_ADJ_REV:
             if (a.have_e) DUDF_GO(SWEEP_ADJ_REV, 1); else DUDF_GO(SWEEP_ADJ_REV, 0);
             break;
+        case SWEEP_FWD_H: if (a.train) DUDF_GO(SWEEP_FWD_H, 1); else DUDF_GO(SWEEP_FWD_H, 0); break;
+        case SWEEP_REV_H: if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0); break;
+        case SWEEP_ADJ_FWD_H: DUDF_GO(SWEEP_ADJ_FWD_H, 0); break;
+        case SWEEP_ADJ_REV_H: DUDF_GO(SWEEP_ADJ_REV_H, 0); break;
         default: return DUDF_E_BADMODE;
     }
 #undef DUDF_GO
@@ -391,7 +490,7 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
 }  // namespace
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st) {
-    DudfProfScope prof(PROF_SWEEP_FWD + which, st);
+    DudfProfScope prof(PROF_SWEEP_FWD + (which & 3), st);
     switch (H) {
         case 32: return launch_h<32>(which, a, st);
         case 64: return launch_h<64>(which, a, st);

@@ -13,7 +13,8 @@
 // operands through LDS per step ([fq][33][4] floats: the 33 makes the per-feature b32 reads
 // conflict-free), and adds its partial tile into dtheta with float atomics at the end (each atomic
 // wave-instruction is two 128-byte row segments — the full-rate shape; 256 KB per workgroup).
-// The bias gradient rides along as one extra MFMA per A fragment against a B operand of ones.
+// The bias gradient rides along on the VALU: running row sums of zbar, masked by x4[column][3] (1 for value
+// columns, 0 for tangent channels and padding), beside the MFMAs.
 // The two thin layers (3 inputs / 1 output) are a bandwidth-bound VALU reduction.
 #include "dudf_internal.h"
 
@@ -30,6 +31,7 @@ constexpr int KTP = 33;         // padded
 
 struct WgradArgs {
     const float *Q, *A, *Z, *S;         // stash arrays
+    const float* x4;                    // [np][4]; x4[c][3] == 1 marks a value column (carries the bias)
     float* dtheta;
     int64_t np, stash_layer, off_hid, hid_stride;
     int steps_total;                    // np / KT
@@ -49,7 +51,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     constexpr int TILE = FQ * KTP * 4;              // floats per staged operand
     constexpr int F4 = FQ * KT;                     // float4 per operand per stage
     constexpr int NLD = (F4 + NTHR - 1) / NTHR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2 buffers][X tile | Y tile]
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2 buffers][X tile | Y tile] + [2][KT] bias flags
+    float* flags = lds + 4 * TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo = wave / W::WI, wi = wave % W::WI;
@@ -77,7 +80,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     const float* Y1 = a.S + (int64_t)j * a.stash_layer;
 
     f32x4 rx[NLD], ry[NLD];
+    float rflag = 0.f;
     auto issue = [&](int pair, int step) {
+        if (tid < KT) rflag = a.x4[((int64_t)step * KT + tid) * 4 + 3];
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int f = tid + NTHR * u;
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
             }
         }
     };
-    auto commit = [&](float* buf) {
+    auto commit = [&](float* buf, float* fl) {
+        if (tid < KT) fl[tid] = rflag;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int f = tid + NTHR * u;
@@ -107,13 +113,14 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
     if (nit > 0) {
         issue(pair_of(0), step_of(0));
-        commit(lds);
+        commit(lds, flags);
     }
     __syncthreads();
     for (int it = 0; it < nit; ++it) {
         const float* buf = lds + (it & 1) * 2 * TILE;
         if (it + 1 < nit) issue(pair_of(it + 1), step_of(it + 1));      // next stage: global -> registers
         const float bflag = (pair_of(it) == 1 && wi == 0) ? 1.f : 0.f;
+        const float* fl = flags + (it & 1) * KT;
         const float* xa[W::MT];
         const float* yb[W::NTL];
 #pragma unroll
@@ -138,11 +145,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
             for (int m = 0; m < W::MT; ++m) {
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) acc[m][n] = mfma32(av[m], bv[n], acc[m][n]);
-                bsum[m] = fmaf(av[m], bflag, bsum[m]);
+                bsum[m] = fmaf(av[m], bflag * fl[pt], bsum[m]);
             }
         }
         // the other buffer was last read in iteration it-1 and every wave is past that iteration's barrier
-        if (it + 1 < nit) commit(lds + ((it + 1) & 1) * 2 * TILE);
+        if (it + 1 < nit) commit(lds + ((it + 1) & 1) * 2 * TILE, flags + ((it + 1) & 1) * KT);
         __syncthreads();
     }
 
@@ -168,12 +175,15 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     }
 }
 
-// ---- first and last layer: thin reductions over points (bandwidth-bound, VALU) -------------------------
+// ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
+//   dW_1[o][d] | db_1[o] = sum_c  q_1[o][c] * gbar[c][d]  +  zbar_1[o][c] * x4[c][d]      (d = 3 is the bias: x4[c][3])
+//   dW_out[f]            = sum_c  A_L[f][c] * x4[c][3]   +  ybar[c] * s_L[f][c]
+//   db_out               = sum_c  ybar[c]
 struct WgradSmallArgs {
     const float *Q, *A, *Z, *S;
-    const float *x, *gbar, *ybar;       // x (n,3); gbar [np][4]; ybar [np]
+    const float *x4, *gbar, *ybar;      // x4 [np][4]; gbar [np][4]; ybar [np]
     float* dtheta;
-    int64_t n, np, stash_layer, off_wo, off_bo;
+    int64_t np, stash_layer, off_wo, off_bo;
     int H, L, have_g;
     int pts_per_block;
 };
@@ -184,8 +194,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// grid.x = point ranges; block = 256 threads = 4 waves; each wave loops over feature quads,
-// lanes run over 64 consecutive points (16-byte granules -> 1 KiB coalesced per load).
+// grid.x = column ranges, grid.y = feature-quad groups; block = 256 threads = 4 waves; each wave loops over
+// feature quads, lanes run over 64 consecutive columns (16-byte granules -> 1 KiB coalesced per load).
 __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int FQ = a.H / 4;
@@ -198,16 +208,15 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
     const int fq_per = (FQ + gridDim.y - 1) / gridDim.y;
     const int fq_lo = blockIdx.y * fq_per, fq_hi = (fq_lo + fq_per < FQ) ? fq_lo + fq_per : FQ;
     for (int fq = fq_lo + wave; fq < fq_hi; fq += 4) {
-        float w1[4][3], b1[4], wo[4];
+        float w1[4][4], wo[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { b1[c] = 0.f; wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = 0.f; }
+        for (int c = 0; c < 4; ++c) { wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = w1[c][3] = 0.f; }
         for (int64_t p = p0 + lane; p < p1; p += 64) {
             const int64_t off = ((int64_t)fq * a.np + p) * 4;
             const f32x4 z = *reinterpret_cast<const f32x4*>(Z0 + off);
             const f32x4 sl = *reinterpret_cast<const f32x4*>(SL + off);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x4 + p * 4);
             const float yb = a.ybar[p];
-            float xv[3] = {0.f, 0.f, 0.f};
-            if (p < a.n) { xv[0] = a.x[p * 3]; xv[1] = a.x[p * 3 + 1]; xv[2] = a.x[p * 3 + 2]; }
             f32x4 qv = {0, 0, 0, 0}, al = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
             if (a.have_g) {
                 qv = *reinterpret_cast<const f32x4*>(Q0 + off);
@@ -217,25 +226,20 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) w1[c][d] += qv[c] * gb[d] + z[c] * xv[d];
-                b1[c] += z[c];
-                wo[c] += al[c] + yb * sl[c];
+                for (int d = 0; d < 4; ++d) w1[c][d] += qv[c] * gb[d] + z[c] * xv[d];
+                wo[c] += al[c] * xv[3] + yb * sl[c];
             }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int f = 4 * fq + c;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
+            for (int d = 0; d < 4; ++d) {
                 const float v = wave_sum(w1[c][d]);
-                if (lane == 0) atomicAdd(a.dtheta + f * 3 + d, v);
+                if (lane == 0) atomicAdd(d < 3 ? a.dtheta + f * 3 + d : a.dtheta + 3 * a.H + f, v);
             }
-            const float vb = wave_sum(b1[c]);
             const float vo = wave_sum(wo[c]);
-            if (lane == 0) {
-                atomicAdd(a.dtheta + 3 * a.H + f, vb);
-                atomicAdd(a.dtheta + a.off_wo + f, vo);
-            }
+            if (lane == 0) atomicAdd(a.dtheta + a.off_wo + f, vo);
         }
     }
     if (wave == 0 && blockIdx.y == 0) {                               // db_out = sum ybar
@@ -250,7 +254,7 @@ template <int H>
 int launch_hidden(const WgradArgs& a, hipStream_t st) {
     using W = WG<H>;
     constexpr int NTHR = 64 * W::WO * W::WI;
-    const size_t smem = 4 * (size_t)(H / 4) * KTP * 4 * sizeof(float);   // 2 buffers x (X tile + Y tile)
+    const size_t smem = (4 * (size_t)(H / 4) * KTP * 4 + 2 * KT) * sizeof(float);   // 2 x (X tile + Y tile) + flags
     const int nl = a.L - 1;
     if (nl <= 0) return 0;
     int nsplit = 256 / nl;                               // one resident workgroup per CU, a single round
@@ -269,9 +273,9 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dtheta, int have_g, hipStream_t st) {
+int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st) {
     WgradArgs a;
-    a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S;
+    a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S; a.x4 = ws + lo.ws_x4;
     a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.np / KT); a.L = lo.L;
     a.have_g = have_g;
@@ -288,8 +292,8 @@ int dudf_launch_wgrad(const DudfLayout& lo, const float* x, float* ws, float* dt
     }
     if (rc) return rc;
     WgradSmallArgs s;
-    s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x = x; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
-    s.dtheta = dtheta; s.n = lo.n; s.np = lo.np; s.stash_layer = lo.stash_layer;
+    s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = a.x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
+    s.dtheta = dtheta; s.np = lo.np; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
     s.pts_per_block = 512;
     const int grid = (int)((lo.np + s.pts_per_block - 1) / s.pts_per_block);

@@ -38,18 +38,22 @@ def gradient(y, x, grad_outputs=None):
 
 
 def hessian(y, x):
-    """reference src/diff_operators.py:187-193.  The forward-over-reverse HIP sweep is the next
-    kernel on the list; until it exists this raises instead of silently running PyTorch autograd."""
-    _source(y, x)
-    raise DudfError("hessian(y, x): the HIP Hessian sweep is not built yet; no CPU/autograd fallback by design")
+    """(1,N,3,3) like reference src/diff_operators.py:187-193: row i = grad(df/dx_i, x).  Forward-over-reverse in
+    the kernels (three tangent columns per point), not repeated autograd.  Plain tensor, like `gradient`."""
+    model, coords = _source(y, x)
+    x2 = coords.detach().reshape(-1, 3)
+    _, _, h = hip_ops.query_hessian(model.hip_cfg, model.flat_parameters(), x2)
+    return h.reshape(coords.shape[:-1] + (3, 3)) if coords.dim() == 3 else h.unsqueeze(0)
 
 
 def divergence(y, x):
-    raise DudfError("divergence: needs the HIP Hessian sweep (not built yet)")
+    raise DudfError("divergence of an arbitrary vector field has no HIP path; for the field's own gradient use laplace")
 
 
 def laplace(y, x):
-    raise DudfError("laplace: needs the HIP Hessian sweep (not built yet)")
+    """div(grad f) = trace of the Hessian — reference src/diff_operators.py:196-198."""
+    h = hessian(y, x)
+    return (h[..., 0, 0] + h[..., 1, 1] + h[..., 2, 2]).unsqueeze(-1)
 
 
 def jacobian(y, x):

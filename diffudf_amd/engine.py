@@ -50,12 +50,14 @@ class TrainEngine:
         if self.world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
-    def loss_and_grad(self, mode, x, normals, sdf, weights, alpha=100.0, n_global=None):
-        """Fills self.terms (global loss terms) and self.dtheta (global gradient); returns self.terms."""
+    def loss_and_grad(self, mode, x, normals, sdf, weights, alpha=100.0, n_global=None, n_hess=0):
+        """Fills self.terms (global loss terms) and self.dtheta (global gradient); returns self.terms.
+        n_hess: for loss_s1 with a Hessian weight, the number of leading on-surface points (C-ABI contract)."""
         ops = self.ops
         n = x.shape[0]
         n_global = n * self.world if n_global is None else n_global
-        ws = ops.workspace_for(self.cfg, n, self.device)
+        ws = ops.workspace_for(self.cfg, n, self.device, n_hess) if n_hess else ops.workspace_for(self.cfg, n, self.device)
+        kw = {"n_hess": n_hess} if n_hess else {}
         if mode == LOSS_S2:
             stats = ops.s2_forward_stats(self.cfg, self.theta, x, sdf, ws)
             self._allreduce(stats)                       # (count, sum, sum sq) of the on-surface predictions
@@ -65,9 +67,9 @@ class TrainEngine:
                               stats, ws, dtheta=self.dtheta)
             self._allreduce(self.dtheta)
         else:
-            terms = ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws)
+            terms = ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws, **kw)
             ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
-                              None, ws, dtheta=self.dtheta)
+                              None, ws, dtheta=self.dtheta, **kw)
             self.terms.copy_(terms)
             self._allreduce(self.flat)                   # one collective: gradient + the four loss scalars
         return self.terms
@@ -77,7 +79,7 @@ class TrainEngine:
         self.ops.adam_step(self.theta, self.dtheta, self.exp_avg, self.exp_avg_sq, self.t, lr, self.betas[0],
                            self.betas[1], self.eps)
 
-    def step(self, mode, x, normals, sdf, weights, alpha=100.0, lr=1e-4, n_global=None):
-        terms = self.loss_and_grad(mode, x, normals, sdf, weights, alpha, n_global)
+    def step(self, mode, x, normals, sdf, weights, alpha=100.0, lr=1e-4, n_global=None, n_hess=0):
+        terms = self.loss_and_grad(mode, x, normals, sdf, weights, alpha, n_global, n_hess)
         self.adam(lr)
         return terms

@@ -18,8 +18,6 @@ def evaluate(model, samples, latent_vec=None, max_batch=64 ** 2, output_size=1, 
     """
     if latent_vec is not None and torch.as_tensor(latent_vec).numel() != 0:
         raise DudfError("evaluate: latent vectors are not part of the HIP path (no reference config uses them)")
-    if hessians is not None:
-        raise DudfError("evaluate(..., hessians=...): the HIP Hessian sweep is not built yet; no fallback by design")
     if output_size != 1:
         raise DudfError("evaluate: output_size must be 1")
     theta = model.flat_parameters()
@@ -28,7 +26,7 @@ def evaluate(model, samples, latent_vec=None, max_batch=64 ** 2, output_size=1, 
         raise DudfError("evaluate: needs the GPU; there is no CPU fallback path")
     n = samples.shape[0]
     evaluations = np.zeros((n, output_size))
-    chunk = max(int(max_batch), 1 << 18)
+    chunk = max(int(max_batch), 1 << 18) if hessians is None else max(int(max_batch), 1 << 16)
     cfg = model.hip_cfg
     head = 0
     while head < n:
@@ -36,7 +34,11 @@ def evaluate(model, samples, latent_vec=None, max_batch=64 ** 2, output_size=1, 
         sub = samples[head:tail]
         sub = sub if torch.is_tensor(sub) else torch.from_numpy(np.ascontiguousarray(sub))
         sub = sub.to(dev).float().reshape(-1, 3)
-        f, g = hip_ops.query(cfg, theta, sub, want_grad=gradients is not None)
+        if hessians is not None:
+            f, g, h = hip_ops.query_hessian(cfg, theta, sub)
+            hessians[head:tail] = h.cpu().numpy()
+        else:
+            f, g = hip_ops.query(cfg, theta, sub, want_grad=gradients is not None)
         evaluations[head:tail, 0] = f.cpu().numpy()
         if gradients is not None:
             gradients[head:tail] = g.cpu().numpy()

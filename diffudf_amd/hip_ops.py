@@ -44,11 +44,11 @@ def _f32(t, what):
 
 
 class Workspace:
-    """Caller-owned scratch for one (cfg, n_points).  Holds the stash between forward and backward."""
+    """Caller-owned scratch for one (cfg, n_points, n_hess).  Holds the stash between forward and backward."""
 
-    def __init__(self, cfg, n, device):
-        self.cfg, self.n = cfg, int(n)
-        self.nbytes = int(_lib.load().dudf_workspace_bytes(ctypes.byref(cfg), self.n))
+    def __init__(self, cfg, n, device, n_hess=0):
+        self.cfg, self.n, self.n_hess = cfg, int(n), int(n_hess)
+        self.nbytes = int(_lib.load().dudf_workspace_bytes_hess(ctypes.byref(cfg), self.n, self.n_hess))
         if self.nbytes == 0:
             _lib.check(-1, "dudf_workspace_bytes")
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
@@ -58,13 +58,13 @@ class Workspace:
 _ws_cache = {}
 
 
-def workspace_for(cfg, n, device):
-    key = (cfg.n_hidden_layers, cfg.hidden, cfg.w0, int(n), str(device))
+def workspace_for(cfg, n, device, n_hess=0):
+    key = (cfg.n_hidden_layers, cfg.hidden, cfg.w0, int(n), str(device), int(n_hess))
     ws = _ws_cache.get(key)
     if ws is None:
         for k in [k for k in _ws_cache if k[:3] == key[:3] and k[4] == key[4]]:
             del _ws_cache[k]                      # one live workspace per network: they are large
-        ws = _ws_cache[key] = Workspace(cfg, n, device)
+        ws = _ws_cache[key] = Workspace(cfg, n, device, n_hess)
     return ws
 
 
@@ -83,18 +83,35 @@ def query(cfg, theta, x, want_grad=True, ws=None):
     return f, g
 
 
+def query_hessian(cfg, theta, x, ws=None):
+    """f (n,), df/dx (n,3), Hessian (n,3,3) [i][k] = d(df/dx_i)/dx_k.  Reference: src/evaluate.py:26-35."""
+    lib = _lib.load()
+    x = _f32(x, "x").view(-1, 3)
+    theta = _f32(theta, "theta")
+    n = x.shape[0]
+    ws = ws or workspace_for(cfg, n, x.device, n_hess=n)
+    f = torch.empty(n, dtype=torch.float32, device=x.device)
+    g = torch.empty(n, 3, dtype=torch.float32, device=x.device)
+    h = torch.empty(n, 3, 3, dtype=torch.float32, device=x.device)
+    rc = lib.dudf_query_hessian(ctypes.byref(cfg), _ptr(theta), _ptr(x), n, _ptr(f), _ptr(g), _ptr(h), _ptr(ws.buf),
+                                ws.nbytes, _stream())
+    _lib.check(rc, "dudf_query_hessian")
+    return f, g, h
+
+
 def _w4(weights):
     w = list(weights) + [0.0] * (4 - len(weights))
     return (ctypes.c_double * 4)(*[float(v) for v in w])
 
 
-def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws):
+def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws, n_hess=0):
+    """n_hess > 0 (loss_s1 with a Hessian weight): the first n_hess points must be exactly the on-surface ones."""
     lib = _lib.load()
     n = x.shape[0]
     terms = torch.empty(4, dtype=torch.float32, device=x.device)
     rc = lib.dudf_loss_forward(ctypes.byref(cfg), mode, _ptr(theta), _ptr(x), _ptr(normals), _ptr(sdf), n,
-                               int(n_global), _w4(weights), float(alpha), _ptr(terms), _ptr(ws.buf), ws.nbytes,
-                               _stream())
+                               int(n_global), int(n_hess), _w4(weights), float(alpha), _ptr(terms), _ptr(ws.buf),
+                               ws.nbytes, _stream())
     _lib.check(rc, "dudf_loss_forward")
     return terms
 
@@ -117,14 +134,14 @@ def s2_terms(stats, weights):
 
 
 def loss_backward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot, stats, ws, dtheta=None,
-                  accumulate=False):
+                  accumulate=False, n_hess=0):
     lib = _lib.load()
     if dtheta is None:
         dtheta = torch.empty_like(theta)
         accumulate = False
     rc = lib.dudf_loss_backward(ctypes.byref(cfg), mode, _ptr(theta), _ptr(x), _ptr(normals), _ptr(sdf), x.shape[0],
-                                int(n_global), _w4(weights), float(alpha), _ptr(cot), _ptr(stats), _ptr(dtheta),
-                                1 if accumulate else 0, _ptr(ws.buf), ws.nbytes, _stream())
+                                int(n_global), int(n_hess), _w4(weights), float(alpha), _ptr(cot), _ptr(stats),
+                                _ptr(dtheta), 1 if accumulate else 0, _ptr(ws.buf), ws.nbytes, _stream())
     _lib.check(rc, "dudf_loss_backward")
     return dtheta
 
@@ -159,11 +176,13 @@ def adam_step(theta, dtheta, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.9
     _lib.check(rc, "dudf_adam_step")
 
 
-def read_stash(cfg, which, layer, n, ws):
-    """Diagnostic: (n,H) copy of one stashed quantity ('s','c','q','e','A','zbar') of hidden layer `layer`."""
+def read_stash(cfg, which, layer, n, ws, channel=0):
+    """Diagnostic: (n,H) copy of one stashed quantity of hidden layer `layer` (channel 1..3 = tangent d/dx_k,
+    Hessian-path points only)."""
     lib = _lib.load()
-    idx = {"s": 0, "c": 1, "q": 2, "e": 3, "A": 4, "zbar": 5, "r": 6}[which]
+    idx = {"s": 0, "c": 1, "q": 2, "e": 3, "A": 4, "zbar": 5, "r": 6, "zs": 7}[which]
     out = torch.empty(n, cfg.hidden, dtype=torch.float32, device=ws.buf.device)
-    rc = lib.dudf_debug_read_stash(ctypes.byref(cfg), idx, layer, n, _ptr(out), _ptr(ws.buf), ws.nbytes, _stream())
+    rc = lib.dudf_debug_read_stash(ctypes.byref(cfg), idx, layer, channel, n, ws.n_hess, _ptr(out), _ptr(ws.buf),
+                                   ws.nbytes, _stream())
     _lib.check(rc, "dudf_debug_read_stash")
     return out

@@ -11,8 +11,11 @@ Each call is ONE forward of the fused HIP path (SIREN sweep, df/dx sweep, per-po
 every term.  The activations stay in the per-network workspace in between, so — like the reference's graph —
 a loss dict must be backpropagated before the next loss call on the same network.
 
-Hessian term of loss_s1 (loss_weights[2] != 0, reference :140-145): needs the Hessian sweep + closed-form
-eigh backward, which is not built yet -> raises (there is deliberately no autograd fallback).
+Hessian term of loss_s1 (loss_weights[2] != 0, reference :140-145): the on-surface points (sdf == 0) take the
+Hessian path of the kernels (forward-over-reverse tangents as three extra columns per point, Jacobi eigh of the
+3x3 lower triangle, closed-form eigh backward); the other points take the plain path.  The C
+ABI wants the on-surface points first, so the batch is permuted once on the device when it is not already in
+the reference sampler's [on | far | near] order.
 """
 import torch
 
@@ -35,12 +38,25 @@ def _prep(model_input, gt):
     return x, normals, sdf
 
 
+def _on_surface_first(x, normals, sdf):
+    """(x, normals, sdf, n_on) with the sdf == 0 points leading (one device->host sync for the count)."""
+    on = sdf == 0
+    n_on = int(on.sum())
+    if n_on == 0 or bool(on[:n_on].all()):
+        return x, normals, sdf, n_on
+    perm = torch.argsort((~on).to(torch.int8), stable=True)
+    return x[perm].contiguous(), normals[perm].contiguous(), sdf[perm].contiguous(), n_on
+
+
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, mode, x, normals, sdf, weights, alpha, n_global, *params):
         cfg = model.hip_cfg
         theta = model.flat_parameters()
-        ws = hip_ops.workspace_for(cfg, x.shape[0], x.device)
+        n_hess = 0
+        if mode == hip_ops.LOSS_S1 and weights[2] != 0:
+            x, normals, sdf, n_hess = _on_surface_first(x, normals, sdf)
+        ws = hip_ops.workspace_for(cfg, x.shape[0], x.device, n_hess=n_hess)
         ws.generation = getattr(ws, "generation", 0) + 1
         stats = None
         if mode == hip_ops.LOSS_S2:
@@ -50,8 +66,8 @@ class _FusedLoss(torch.autograd.Function):
                 reducer(stats)
             terms = hip_ops.s2_terms(stats, weights)
         else:
-            terms = hip_ops.loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws)
-        ctx.model, ctx.mode, ctx.ws, ctx.stats = model, mode, ws, stats
+            terms = hip_ops.loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws, n_hess=n_hess)
+        ctx.model, ctx.mode, ctx.ws, ctx.stats, ctx.n_hess = model, mode, ws, stats, n_hess
         ctx.args = (x, normals, sdf, list(weights), alpha, n_global)
         ctx.stamp = ws.generation
         return terms
@@ -67,7 +83,7 @@ class _FusedLoss(torch.autograd.Function):
         cot[:grad_terms.numel()] = grad_terms.float()
         theta = model.flat_parameters()
         dtheta = hip_ops.loss_backward(model.hip_cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot,
-                                       ctx.stats, ws)
+                                       ctx.stats, ws, n_hess=ctx.n_hess)
         return (None,) * 8 + tuple(model.split_flat(dtheta))
 
 
@@ -81,10 +97,6 @@ def _run(model, mode, model_input, gt, loss_weights, alpha, keys):
 
 def loss_s1(model, model_input, gt, loss_weights, alpha):
     """Hyperbolic-scaled UDF loss, stage 1 — reference src/loss_functions.py:123-155."""
-    if loss_weights[2] != 0:
-        raise DudfError("loss_s1 with a non-zero hessian_constraint weight needs the HIP Hessian + eigh-backward "
-                        "kernels, which are not built yet (no autograd fallback by design); use "
-                        "loss_weights[2] = 0 for the Eikonal-only loss")
     return _run(model, hip_ops.LOSS_S1, model_input, gt, loss_weights, alpha, _S1_KEYS)
 
 

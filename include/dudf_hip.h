@@ -28,7 +28,7 @@ extern "C" {
 #define DUDF_E_BADCFG   (-1)   /* unsupported network shape (hidden widths must be equal, in {32,64,128,256}) */
 #define DUDF_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define DUDF_E_BADMODE  (-3)
-#define DUDF_E_UNSUPPORTED (-4) /* e.g. loss_s1 with a non-zero Hessian weight: not built yet */
+#define DUDF_E_UNSUPPORTED (-4)
 
 /* loss selector — reference src/loss_functions.py:123 (loss_s1), :106 (loss_s2), :82 (loss_siren) */
 #define DUDF_LOSS_S1    0
@@ -45,8 +45,10 @@ typedef struct dudf_net_cfg {
 /* number of floats in theta for this cfg (461 825 for 8x256) */
 int64_t dudf_theta_count(const dudf_net_cfg* cfg);
 
-/* bytes of workspace needed for a local batch of n points (training: stash of all sweeps) */
+/* bytes of workspace needed for a local batch of n points (training: stash of all sweeps);
+ * the _hess form when the first n_hess of them take the Hessian path (4 columns each instead of 1) */
 size_t dudf_workspace_bytes(const dudf_net_cfg* cfg, int64_t n);
+size_t dudf_workspace_bytes_hess(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess);
 
 /* Replaces `model(x)['model_out']` + `gradient(y, x)` as used by the chunk loop of
  * reference src/evaluate.py:26-35 (SIREN.forward src/model.py:116-135; gradient
@@ -54,15 +56,28 @@ size_t dudf_workspace_bytes(const dudf_net_cfg* cfg, int64_t n);
 int dudf_query(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
                float* out_f, float* out_g, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Value, df/dx and the Hessian d2f/dx_i dx_k of every point — replaces `model(x)`, `gradient(y,x)` and
+ * `hessian(y,x)` of the chunk loop in reference src/evaluate.py:26-35 (hessian: src/diff_operators.py:187-193,
+ * rows h_i = grad(g[:,i], x)).  Forward-over-reverse with three tangent channels (8 F0 flops per point).
+ * out_h (n,3,3) row-major [i][k]; workspace of dudf_workspace_bytes_hess(cfg, n, n). */
+int dudf_query_hessian(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+                       float* out_f, float* out_g, float* out_h, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* Forward half of loss_s1 / loss_siren (reference src/loss_functions.py:123-155, :82-104):
  * SIREN forward, df/dx, the four weighted loss terms.  out_terms (device, 4 floats) receives
  * THIS RANK's share  sum_local(term_i) * weight / n_global  in the reference's dict order
  * (s1: sdf_on_surf, sdf_off_surf, hessian_constraint, grad_constraint;
  *  siren: sdf_on_surf, sdf_off_surf, normal_constraint, grad_constraint).
- * weights: host, 4 doubles.  The activations needed by dudf_loss_backward stay in `workspace`. */
+ * weights: host, 4 doubles.  The activations needed by dudf_loss_backward stay in `workspace`.
+ * n_hess: loss_s1 with weights[2] != 0 (hessian_constraint, reference :140-145: eigh of the Hessian, top
+ * eigenvector against the normal, on-surface points only) — the caller orders the batch so that the on-surface
+ * points (sdf == 0) are EXACTLY the first n_hess (the reference sampler already yields [on | far | near],
+ * src/dataset.py:55-70); they take the Hessian path (4 columns each), the others the plain path.  0 otherwise.
+ * Workspace: dudf_workspace_bytes_hess(cfg, n_local, n_hess). */
 int dudf_loss_forward(const dudf_net_cfg* cfg, int mode, const float* theta,
                       const float* x, const float* normals, const float* sdf,
-                      int64_t n_local, int64_t n_global, const double* weights, double alpha,
+                      int64_t n_local, int64_t n_global, int64_t n_hess, const double* weights, double alpha,
                       float* out_terms, void* workspace, size_t workspace_bytes, void* stream);
 
 /* loss_s2 (reference src/loss_functions.py:106-121) needs the mean/std of the on-surface
@@ -83,7 +98,7 @@ int dudf_s2_terms(const double* stats, const double* weights, float* out_terms, 
  * stats: device, 3 doubles (s2 only, else NULL). */
 int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta,
                        const float* x, const float* normals, const float* sdf,
-                       int64_t n_local, int64_t n_global, const double* weights, double alpha,
+                       int64_t n_local, int64_t n_global, int64_t n_hess, const double* weights, double alpha,
                        const float* cot, const double* stats, float* dtheta, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
@@ -106,8 +121,9 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
                    void* stream);
 
 /* Test/diagnostic hook: copy one stashed per-layer quantity of the last sweep into out (n,H) row-major.
- * which: 0 s_l, 1 c_l, 2 q_l, 3 e_l, 4 A_l, 5 zbar_l, 6 r_l; layer: 0-based hidden layer. */
-int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int64_t n,
+ * which: 0 S (h|hdot), 1 C, 2 Q (q|qdot), 3 E, 4 A (A|Adot), 5 Z (zbar|zdotbar), 6 R (r | a|adot), 7 ZS (s|zdot);
+ * layer: 0-based hidden layer; channel: 0 value, 1..3 tangent (Hessian-path points only). */
+int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int channel, int64_t n, int64_t n_hess,
                           float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement hook (bench.py): while enabled, every kernel the library launches is bracketed by HIP

@@ -20,8 +20,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")          # `src.*` must resolve to the REFERENCE here, not to this repo's shim
+sys.path.append(REPO)
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO] + [REPO]
 
 from src.model import SIREN                                     # noqa: E402  (reference)
 from src.diff_operators import gradient, hessian                # noqa: E402  (reference)
@@ -136,7 +137,8 @@ def main():
     out = {}
     hid = [64] * 4
     p32 = synth.siren_params(hid, seed=11, dtype=np.float32)
-    for name, mode, w, lr in (("s1eik", "s1", [1e4, 1e4, 0.0, 1e3], 1e-4), ("s2", "s2", [1e5, 1e5], 1e-6)):
+    for name, mode, w, lr in (("s1eik", "s1", [1e4, 1e4, 0.0, 1e3], 1e-4), ("s2", "s2", [1e5, 1e5], 1e-6),
+                              ("s1full", "s1", [1e4, 1e4, 1e4, 1e3], 1e-4)):
         for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
             hist, theta = trajectory(hid, p32, 384, 20, lr, mode, w, dt, seed=11)
             out[f"{name}_{tag}_hist"] = hist

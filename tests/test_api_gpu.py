@@ -43,7 +43,10 @@ def batch(n, seed, step=0):
     return (x, nrm, sdf), (t(x), t(nrm), t(sdf))
 
 
-@pytest.mark.parametrize("case", ["s1eik", "s2", "siren"])
+W_S1FULL = [1e4, 1e4, 1e4, 1e3]
+
+
+@pytest.mark.parametrize("case", ["s1eik", "s1full", "s1full_shuffled", "s2", "siren"])
 def test_loss_dict_and_param_grads(case):
     from src.loss_functions import loss_s1, loss_s2, loss_siren
     hidden = [256] * 8
@@ -53,6 +56,14 @@ def test_loss_dict_and_param_grads(case):
     if case == "s1eik":
         loss = loss_s1(model, xd, gt, W_S1EIK, 100); mode, w = "s1", W_S1EIK
         assert list(loss) == ["sdf_on_surf", "sdf_off_surf", "hessian_constraint", "grad_constraint"]
+    elif case.startswith("s1full"):
+        if case.endswith("shuffled"):           # any point order works at the Python level
+            perm = np.random.default_rng(0).permutation(x.shape[0])
+            x, nrm, sdf = x[perm], nrm[perm], sdf[perm]
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].to("cuda:0")  # noqa: E731
+            xd, nd, sd = t(x), t(nrm), t(sdf)
+            gt = {"normals": nd, "sdf": sd}
+        loss = loss_s1(model, xd, gt, W_S1FULL, 100); mode, w = "s1", W_S1FULL
     elif case == "s2":
         loss = loss_s2(model, xd, gt, W_S2, 100); mode, w = "s2", W_S2
         assert list(loss) == ["sdf_on_surf", "std_on_surf"]
@@ -68,7 +79,7 @@ def test_loss_dict_and_param_grads(case):
     t_ref, g_ref, _ = O.loss_and_grad(mode, P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), w, 100.0)
     assert rel([v.item() for v in loss.values()], [float(v) for v in t_ref.values()]) < 2e-5
     got = np.concatenate([p.grad.detach().reshape(-1).cpu().numpy() for p in model.parameters()])
-    assert rel(got, flat(g_ref)) < 1e-4
+    assert rel(got, flat(g_ref)) < (5e-4 if case.startswith("s1full") else 1e-4)
     names = [n for n, _ in model.named_parameters()]
     assert names[0] == "net.0.0.weight" and names[-1] == "net.8.0.bias"
 
@@ -79,7 +90,8 @@ def test_adam_trajectory_follows_reference_fixture(golden_dir):
     from src.loss_functions import loss_s1, loss_s2
     G = np.load(os.path.join(golden_dir, "g3_traj.npz"))
     hidden = list(G["hidden"]); n = int(G["n_points"]); seed = int(G["batch_seed"])
-    for name, fn, w, lr in (("s1eik", loss_s1, W_S1EIK, 1e-4), ("s2", loss_s2, W_S2, 1e-6)):
+    for name, fn, w, lr in (("s1eik", loss_s1, W_S1EIK, 1e-4), ("s2", loss_s2, W_S2, 1e-6),
+                            ("s1full", loss_s1, W_S1FULL, 1e-4)):
         model, _ = make_model(hidden, int(G["param_seed"]))
         opt = torch.optim.Adam(lr=lr, params=model.parameters())
         hist = []
@@ -99,8 +111,13 @@ def test_adam_trajectory_follows_reference_fixture(golden_dir):
         e_theta = rel(model.flat_parameters().cpu().numpy(), G[f"{name}_f64_theta"])
         print(f"{name}: trajectory loss err {e_hist:.2e} theta err {e_theta:.2e} (reference fp32-vs-fp64: "
               f"{np.abs(G[name + '_f32_hist'] - ref).max() / np.abs(ref).max():.2e})")
-        assert e_hist < 1e-4
-        assert e_theta < 1e-4
+        # With the Hessian/eigenvector term on, the trajectory is chaotic in fp32: the reference's OWN fp32 run
+        # leaves its fp64 run by 3e-2 (loss) / 2e-3 (theta) within 20 steps (1/(lam_2-lam_j) factors, |cos| kinks).
+        # The bar there is therefore the reference's own drift, not 1e-4.
+        ref_drift_h = np.abs(G[name + "_f32_hist"] - ref).max() / np.abs(ref).max()
+        ref_drift_t = rel(G[name + "_f32_theta"], G[f"{name}_f64_theta"])
+        assert e_hist < max(1e-4, 2.0 * ref_drift_h)
+        assert e_theta < max(1e-4, 2.0 * ref_drift_t)
 
 
 def test_8x256_trajectory_follows_reference_fixture(golden_dir):
@@ -138,8 +155,8 @@ def test_forward_gradient_evaluate_contract(golden_dir):
     assert g.shape == xin.shape
     assert rel(y.detach().cpu().numpy()[0], G["values"]) < 2e-5
     assert rel(g.cpu().numpy()[0], G["gradients"]) < 5e-5
-    with pytest.raises(DudfError):
-        hessian(y, xin)
+    hs = hessian(y, xin)
+    assert hs.shape == (1, n ** 3, 3, 3) and rel(hs.cpu().numpy()[0], G["hessians"]) < 1e-4
     # (M,3) inputs as reference src/render_mc.py:340 uses them
     y2 = model(torch.from_numpy(grid).cuda())["model_out"]
     assert y2.shape == (n ** 3, 1) and torch.equal(y2.reshape(-1), y.reshape(-1))
@@ -148,8 +165,9 @@ def test_forward_gradient_evaluate_contract(golden_dir):
     assert vals.dtype == np.float64 and vals.shape == (n ** 3, 1)
     assert rel(vals, G["values"]) < 2e-5 and rel(grads, G["gradients"]) < 5e-5
     assert np.allclose(inverse("tanh", np.abs(vals), 100), G["inv_tanh"], rtol=1e-4, atol=1e-7)
-    with pytest.raises(DudfError):
-        evaluate(model, grid, device=torch.device("cuda:0"), hessians=np.zeros((n ** 3, 3, 3)))
+    hess = np.zeros((n ** 3, 3, 3)); grads2 = np.zeros((n ** 3, 3))
+    vals2 = evaluate(model, grid, device=torch.device("cuda:0"), gradients=grads2, hessians=hess)
+    assert rel(hess, G["hessians"]) < 1e-4 and rel(grads2, G["gradients"]) < 5e-5 and rel(vals2, G["values"]) < 2e-5
 
 
 def test_custom_loss_through_fields():

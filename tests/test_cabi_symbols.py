@@ -35,8 +35,12 @@ def test_host_only_calls():
     cfg = _lib.NetCfg(3, 8, 256, 30.0)
     assert lib.dudf_theta_count(ctypes.byref(cfg)) == 461825
     nb = lib.dudf_workspace_bytes(ctypes.byref(cfg), 29970)
-    np_ = (29970 + 127) // 128 * 128
+    np_ = (29970 + 63) // 64 * 64
     assert nb >= 7 * 8 * 256 * np_ * 4
+    nbh = lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 29970, 9990)       # on-surface third on the Hessian path
+    cols = (4 * 9990 + 63) // 64 * 64 + (19980 + 63) // 64 * 64
+    assert nbh >= 8 * 8 * 256 * cols * 4
+    assert lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 10, 11) == 0
     bad = _lib.NetCfg(3, 8, 100, 30.0)
     assert lib.dudf_theta_count(ctypes.byref(bad)) == -1
     assert lib.dudf_workspace_bytes(ctypes.byref(bad), 10) == 0

@@ -122,6 +122,44 @@ def test_loss_s2(hip, hidden, n, seed):
     assert et < 2e-5 and ed < TOL_DTHETA
 
 
+TOL_H = 2e-5
+W_S1FULL = [1e4, 1e4, 1e4, 1e3]
+
+
+@pytest.mark.parametrize("hidden,n,seed", NETS)
+def test_query_hessian(hip, hidden, n, seed):
+    P, theta, x, _, _ = setup(hidden, n, seed)
+    cfg = hip.make_cfg(hidden)
+    f, g, h = hip.query_hessian(cfg, dev(theta), dev(x))
+    xs = x.astype(np.float64)
+    y_ref, g_ref, H_ref = O.query(P, xs, want_grad=True, want_hess=True)
+    ef, eg, eh = rel(f.cpu().numpy(), y_ref), rel(g.cpu().numpy(), g_ref), rel(h.cpu().numpy(), H_ref)
+    print(f"hessian {hidden[0]}x{len(hidden)} n={n}: f {ef:.2e} g {eg:.2e} H {eh:.2e}")
+    assert ef < TOL_F and eg < TOL_G and eh < TOL_H
+
+
+@pytest.mark.parametrize("hidden,n,seed", NETS)
+def test_loss_s1_with_hessian_term(hip, hidden, n, seed):
+    """The full reference training loss (configs/train_cfg.json weights): Hessian + eigh + its backward."""
+    P, theta, x, nrm, sdf = setup(hidden, n, seed)
+    n_on = int((sdf[:, 0] == 0).sum())
+    assert (sdf[:n_on, 0] == 0).all() and n_on == n // 3
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda", n_hess=n_on)
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    terms = hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, ws, n_hess=n_on)
+    t_ref, g_ref, dbg = O.loss_and_grad("s1", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64),
+                                        W_S1FULL, 100.0)
+    t_ref = np.array([float(v) for v in t_ref.values()])
+    et = rel(terms.cpu().numpy(), t_ref)
+    dth = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, torch.ones(4, device="cuda"), None,
+                            ws, n_hess=n_on)
+    ed = rel(dth.cpu().numpy(), flat(g_ref))
+    print(f"s1full {hidden[0]}x{len(hidden)} n={n}: terms {et:.2e} dtheta {ed:.2e}")
+    assert et < TOL_TERM
+    assert ed < 5e-4            # the reference's own fp32 noise with the Hessian term on is 6e-5 (BASELINE.md §2)
+
+
 def test_against_committed_reference_fixture(hip, golden_dir):
     """HIP vs the reference's own fp32 outputs (golden fixture), not just vs the oracle."""
     G = np.load(os.path.join(golden_dir, "g2_8x256.npz"))
@@ -160,8 +198,8 @@ def test_unsupported_configs_fail_loudly(hip):
     ws = hip.workspace_for(cfg, 128, "cuda")
     z = torch.zeros(128, 3, device="cuda")
     th = torch.zeros(hip.theta_count(cfg), device="cuda")
-    with pytest.raises(_lib.DudfError):
-        hip.loss_forward(cfg, hip.LOSS_S1, th, z, z, z[:, 0].contiguous(), 128, [1e4, 1e4, 1e4, 1e3], 100.0, ws)
+    with pytest.raises(_lib.DudfError):      # a Hessian range with a loss that has no Hessian term
+        hip.loss_forward(cfg, hip.LOSS_SIREN, th, z, z, z[:, 0].contiguous(), 128, [1, 1, 1, 1], 100.0, ws, n_hess=4)
     with pytest.raises(_lib.DudfError):
         hip.make_cfg([64, 32])
     with pytest.raises(_lib.DudfError):

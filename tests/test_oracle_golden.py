@@ -109,7 +109,7 @@ def test_g3_trajectory_small_net(golden_dir):
     G = np.load(os.path.join(golden_dir, "g3_traj.npz"))
     hid = list(G["hidden"])
     P32 = synth.siren_params(hid, seed=int(G["param_seed"]), dtype=np.float32)
-    for name, mode, w, lr in (("s1eik", "s1", W_S1EIK, 1e-4), ("s2", "s2", W_S2, 1e-6)):
+    for name, mode, w, lr in (("s1eik", "s1", W_S1EIK, 1e-4), ("s2", "s2", W_S2, 1e-6), ("s1full", "s1", W_S1FULL, 1e-4)):
         theta = synth.flatten_params(P32, dtype=np.float64)
         m = np.zeros_like(theta); v = np.zeros_like(theta)
         hist = []
