@@ -120,11 +120,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DUDF_TEST_SHARE_GPU=1: functional check of the N>1 path on a ONE-GPU box (all ranks on cuda:0, gloo instead of
+    # RCCL, which refuses two ranks on one device).  Never set for a measurement.
+    share = os.environ.get("DUDF_TEST_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if share:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
 
     from diffudf_amd import _lib, hip_ops, synth
     from diffudf_amd.engine import TrainEngine
@@ -138,6 +145,7 @@ def main():
     lib = _lib.load()
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()

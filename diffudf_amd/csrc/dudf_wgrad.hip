@@ -13,8 +13,8 @@
 // operands through LDS per step ([fq][33][4] floats: the 33 makes the per-feature b32 reads
 // conflict-free), and adds its partial tile into dtheta with float atomics at the end (each atomic
 // wave-instruction is two 128-byte row segments — the full-rate shape; 256 KB per workgroup).
-// The bias gradient rides along on the VALU: running row sums of zbar, masked by x4[column][3] (1 for value
-// columns, 0 for tangent channels and padding), beside the MFMAs.
+// The bias gradient rides along on the VALU beside the MFMAs: running row sums of zbar over the value columns
+// (every column on the plain range, channel 0 of each quad on the Hessian range; padding columns hold zeros).
 // The two thin layers (3 inputs / 1 output) are a bandwidth-bound VALU reduction.
 #include "dudf_internal.h"
 
@@ -31,7 +31,7 @@ constexpr int KTP = 33;         // padded
 
 struct WgradArgs {
     const float *Q, *A, *Z, *S;         // stash arrays
-    const float* x4;                    // [np][4]; x4[c][3] == 1 marks a value column (carries the bias)
+    int64_t ncol_h;                     // columns [0, ncol_h) are Hessian quads: only channel 0 (col % 4 == 0) carries the bias
     float* dtheta;
     int64_t np, stash_layer, off_hid, hid_stride;
     int steps_total;                    // np / KT
@@ -51,8 +51,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     constexpr int TILE = FQ * KTP * 4;              // floats per staged operand
     constexpr int F4 = FQ * KT;                     // float4 per operand per stage
     constexpr int NLD = (F4 + NTHR - 1) / NTHR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2 buffers][X tile | Y tile] + [2][KT] bias flags
-    float* flags = lds + 4 * TILE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2 buffers][X tile | Y tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo = wave / W::WI, wi = wave % W::WI;
@@ -80,9 +79,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     const float* Y1 = a.S + (int64_t)j * a.stash_layer;
 
     f32x4 rx[NLD], ry[NLD];
-    float rflag = 0.f;
     auto issue = [&](int pair, int step) {
-        if (tid < KT) rflag = a.x4[((int64_t)step * KT + tid) * 4 + 3];
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int f = tid + NTHR * u;
@@ -94,8 +91,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
             }
         }
     };
-    auto commit = [&](float* buf, float* fl) {
-        if (tid < KT) fl[tid] = rflag;
+    auto commit = [&](float* buf) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int f = tid + NTHR * u;
@@ -113,14 +109,18 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
     if (nit > 0) {
         issue(pair_of(0), step_of(0));
-        commit(lds, flags);
+        commit(lds);
     }
     __syncthreads();
     for (int it = 0; it < nit; ++it) {
         const float* buf = lds + (it & 1) * 2 * TILE;
         if (it + 1 < nit) issue(pair_of(it + 1), step_of(it + 1));      // next stage: global -> registers
+        // bias mask of this stage's columns: k index 2*kk+hh is a value column always (plain range) or when
+        // (2*kk+hh) % 4 == 0 (Hessian range: stages never straddle the two ranges)
         const float bflag = (pair_of(it) == 1 && wi == 0) ? 1.f : 0.f;
-        const float* fl = flags + (it & 1) * KT;
+        const bool hstage = (int64_t)step_of(it) * KT < a.ncol_h;
+        const float f_even = hstage ? (hh == 0 ? bflag : 0.f) : bflag;
+        const float f_odd = hstage ? 0.f : bflag;
         const float* xa[W::MT];
         const float* yb[W::NTL];
 #pragma unroll
@@ -145,11 +145,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
             for (int m = 0; m < W::MT; ++m) {
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) acc[m][n] = mfma32(av[m], bv[n], acc[m][n]);
-                bsum[m] = fmaf(av[m], bflag * fl[pt], bsum[m]);
+                bsum[m] = fmaf(av[m], (kk & 1) ? f_odd : f_even, bsum[m]);
             }
         }
         // the other buffer was last read in iteration it-1 and every wave is past that iteration's barrier
-        if (it + 1 < nit) commit(lds + ((it + 1) & 1) * 2 * TILE, flags + ((it + 1) & 1) * KT);
+        if (it + 1 < nit) commit(lds + ((it + 1) & 1) * 2 * TILE);
         __syncthreads();
     }
 
@@ -254,7 +254,7 @@ template <int H>
 int launch_hidden(const WgradArgs& a, hipStream_t st) {
     using W = WG<H>;
     constexpr int NTHR = 64 * W::WO * W::WI;
-    const size_t smem = (4 * (size_t)(H / 4) * KTP * 4 + 2 * KT) * sizeof(float);   // 2 x (X tile + Y tile) + flags
+    const size_t smem = 4 * (size_t)(H / 4) * KTP * 4 * sizeof(float);   // 2 buffers x (X tile + Y tile)
     const int nl = a.L - 1;
     if (nl <= 0) return 0;
     int nsplit = 256 / nl;                               // one resident workgroup per CU, a single round
@@ -275,7 +275,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
 
 int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st) {
     WgradArgs a;
-    a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S; a.x4 = ws + lo.ws_x4;
+    a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S; a.ncol_h = lo.ncol_h;
     a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.np / KT); a.L = lo.L;
     a.have_g = have_g;
@@ -292,7 +292,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     }
     if (rc) return rc;
     WgradSmallArgs s;
-    s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = a.x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
+    s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
     s.pts_per_block = 512;
