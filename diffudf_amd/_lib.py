@@ -53,6 +53,9 @@ SYMBOLS = {
                                             ctypes.c_size_t, _P]),
     "dudf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_double, _P]),
+    "dudf_sample_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                         _P, _P, _P, _P]),
     "dudf_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "dudf_profile_dump": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,

@@ -1,0 +1,168 @@
+// Per-step training batch on the GPU — replaces reference src/dataset.py:14-70 `sampleTrainingData`
+// (open3d RaycastingScene on the CPU) for triangle meshes small enough for a brute-force distance
+// (the beetle has 2 053 triangles; 20 k queries x 2 k triangles is ~2.5 GFLOP, tens of microseconds).
+//
+// Batch = [on-surface | far | near]  (reference :52-68):
+//   on   : a random point of the precomputed surface cloud, its triangle normal, sdf = 0
+//   far  : uniform in [-1,1]^3, normal 0, sdf = distance to the mesh
+//   near : one of this step's on-surface samples moved along its normal by N(0, 0.01), normal 0,
+//          sdf = distance to the mesh
+// The reference stores the SIGNED distance open3d returns; every consumer (loss_s1 / loss_s2,
+// src/loss_functions.py:131-136) is even in it, so the unsigned distance is written.
+//
+// Random numbers are counter-based — a pure function of (seed, step, stream, GLOBAL sample index), the same
+// splitmix64 construction as diffudf_amd/synth.py — so rank r of W produces exactly its slice of the global batch
+// and the numpy restatement in oracle/sampler_oracle.py reproduces every sample.
+#include "dudf_internal.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint64_t stream) {
+    return splitmix64(seed * 0x100000001B3ull + stream);
+}
+__device__ __forceinline__ double uniform01(uint64_t key, uint64_t idx) {
+    uint64_t b = splitmix64(idx ^ key);
+    b = splitmix64(b + key);
+    return (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct SampleArgs {
+    const float *tri, *pc_pos, *pc_nrm;
+    float *x, *normals, *sdf;
+    int64_t n_tri, n_pc;
+    int64_t n_on, n_far, n_near;           // GLOBAL stratum sizes
+    int64_t on0, on1, far0, far1, near0, near1;   // this rank's [begin, end) inside each stratum
+    uint64_t k_on, k_fx, k_fy, k_fz, k_pick, k_n1, k_n2;
+};
+
+// squared distance from p to triangle (a,b,c): closest point by Voronoi regions of the triangle
+__device__ __forceinline__ float tri_dist2(float px, float py, float pz, const float* t) {
+    const float ax = t[0], ay = t[1], az = t[2];
+    const float abx = t[3] - ax, aby = t[4] - ay, abz = t[5] - az;
+    const float acx = t[6] - ax, acy = t[7] - ay, acz = t[8] - az;
+    const float apx = px - ax, apy = py - ay, apz = pz - az;
+    const float d1 = abx * apx + aby * apy + abz * apz;
+    const float d2 = acx * apx + acy * apy + acz * apz;
+    float cx, cy, cz;                                  // closest point - a
+    if (d1 <= 0.f && d2 <= 0.f) { cx = cy = cz = 0.f; }
+    else {
+        const float bpx = apx - abx, bpy = apy - aby, bpz = apz - abz;
+        const float d3 = abx * bpx + aby * bpy + abz * bpz;
+        const float d4 = acx * bpx + acy * bpy + acz * bpz;
+        if (d3 >= 0.f && d4 <= d3) { cx = abx; cy = aby; cz = abz; }
+        else {
+            const float vc = d1 * d4 - d3 * d2;
+            if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+                const float v = d1 / (d1 - d3);
+                cx = v * abx; cy = v * aby; cz = v * abz;
+            } else {
+                const float cpx = apx - acx, cpy = apy - acy, cpz = apz - acz;
+                const float d5 = abx * cpx + aby * cpy + abz * cpz;
+                const float d6 = acx * cpx + acy * cpy + acz * cpz;
+                if (d6 >= 0.f && d5 <= d6) { cx = acx; cy = acy; cz = acz; }
+                else {
+                    const float vb = d5 * d2 - d1 * d6;
+                    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+                        const float w = d2 / (d2 - d6);
+                        cx = w * acx; cy = w * acy; cz = w * acz;
+                    } else {
+                        const float va = d3 * d6 - d5 * d4;
+                        if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+                            const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+                            cx = abx + w * (acx - abx); cy = aby + w * (acy - aby); cz = abz + w * (acz - abz);
+                        } else {
+                            const float den = 1.f / (va + vb + vc);
+                            const float v = vb * den, w = vc * den;
+                            cx = abx * v + acx * w; cy = aby * v + acy * w; cz = abz * v + acz * w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const float dx = apx - cx, dy = apy - cy, dz = apz - cz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+constexpr int TRI_TILE = 256;
+
+__global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
+    __shared__ float tl[TRI_TILE * 9];
+    const int64_t n_on_l = a.on1 - a.on0, n_far_l = a.far1 - a.far0, n_near_l = a.near1 - a.near0;
+    const int64_t n_l = n_on_l + n_far_l + n_near_l;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n_l;
+    float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    bool query = false;
+    if (live) {
+        if (i < n_on_l) {
+            const int64_t g = a.on0 + i;
+            const int64_t c = (int64_t)(uniform01(a.k_on, (uint64_t)g) * (double)a.n_pc);
+            px = a.pc_pos[c * 3]; py = a.pc_pos[c * 3 + 1]; pz = a.pc_pos[c * 3 + 2];
+            nx = a.pc_nrm[c * 3]; ny = a.pc_nrm[c * 3 + 1]; nz = a.pc_nrm[c * 3 + 2];
+        } else if (i < n_on_l + n_far_l) {
+            const uint64_t g = (uint64_t)(a.far0 + (i - n_on_l));
+            px = (float)(uniform01(a.k_fx, g) * 2.0 - 1.0);
+            py = (float)(uniform01(a.k_fy, g) * 2.0 - 1.0);
+            pz = (float)(uniform01(a.k_fz, g) * 2.0 - 1.0);
+            query = true;
+        } else {
+            const uint64_t g = (uint64_t)(a.near0 + (i - n_on_l - n_far_l));
+            const int64_t k = (int64_t)(uniform01(a.k_pick, g) * (double)a.n_on);       // which on-surface sample
+            const int64_t c = (int64_t)(uniform01(a.k_on, (uint64_t)k) * (double)a.n_pc);
+            const double u1 = uniform01(a.k_n1, g), u2 = uniform01(a.k_n2, g);
+            const float off = (float)(0.01 * sqrt(-2.0 * log1p(-u1)) * cos(6.283185307179586476925 * u2));
+            px = __fadd_rn(a.pc_pos[c * 3], __fmul_rn(a.pc_nrm[c * 3], off));
+            py = __fadd_rn(a.pc_pos[c * 3 + 1], __fmul_rn(a.pc_nrm[c * 3 + 1], off));
+            pz = __fadd_rn(a.pc_pos[c * 3 + 2], __fmul_rn(a.pc_nrm[c * 3 + 2], off));
+            query = true;
+        }
+    }
+    float best = 3.0e38f;
+    for (int64_t t0 = 0; t0 < a.n_tri; t0 += TRI_TILE) {
+        const int cnt = (int)((a.n_tri - t0 < TRI_TILE) ? a.n_tri - t0 : TRI_TILE);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 9; e += blockDim.x) tl[e] = a.tri[t0 * 9 + e];
+        __syncthreads();
+        if (query)
+            for (int t = 0; t < cnt; ++t) best = fminf(best, tri_dist2(px, py, pz, tl + t * 9));
+    }
+    if (live) {
+        a.x[i * 3] = px; a.x[i * 3 + 1] = py; a.x[i * 3 + 2] = pz;
+        a.normals[i * 3] = nx; a.normals[i * 3 + 1] = ny; a.normals[i * 3 + 2] = nz;
+        a.sdf[i] = query ? sqrtf(best) : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int dudf_sample_batch(const float* tri, int64_t n_tri, const float* pc_pos, const float* pc_nrm,
+                                 int64_t n_pc, int64_t n_on, int64_t n_far, int64_t n_near, uint64_t seed,
+                                 uint64_t step, int rank, int world, float* x, float* normals, float* sdf,
+                                 void* stream) {
+    if (n_tri <= 0 || n_pc <= 0 || world < 1 || rank < 0 || rank >= world || n_on < 0 || n_far < 0 || n_near < 0)
+        return DUDF_E_BADCFG;
+    if (n_near > 0 && n_on == 0) return DUDF_E_BADCFG;
+    SampleArgs a;
+    a.tri = tri; a.pc_pos = pc_pos; a.pc_nrm = pc_nrm; a.x = x; a.normals = normals; a.sdf = sdf;
+    a.n_tri = n_tri; a.n_pc = n_pc; a.n_on = n_on; a.n_far = n_far; a.n_near = n_near;
+    auto lo = [&](int64_t m) { return m * rank / world; };
+    auto hi = [&](int64_t m) { return m * (rank + 1) / world; };
+    a.on0 = lo(n_on); a.on1 = hi(n_on); a.far0 = lo(n_far); a.far1 = hi(n_far); a.near0 = lo(n_near); a.near1 = hi(n_near);
+    const uint64_t base = 1000ull * step;
+    a.k_on = stream_key(seed, base + 400); a.k_fx = stream_key(seed, base + 401); a.k_fy = stream_key(seed, base + 402);
+    a.k_fz = stream_key(seed, base + 403); a.k_pick = stream_key(seed, base + 404);
+    a.k_n1 = stream_key(seed, base + 405); a.k_n2 = stream_key(seed, base + 406);
+    const int64_t n_l = (a.on1 - a.on0) + (a.far1 - a.far0) + (a.near1 - a.near0);
+    if (n_l == 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}

@@ -9,9 +9,10 @@ with N = int(B*p0) + 2*(int(B*p1)//2) points ordered [on-surface | far | near] (
 This is also the SHARDING SEAM of the multi-GPU path: `rank`/`world` select this rank's equal slice of each
 of the three strata, so every rank keeps the on/far/near mix and the union over ranks is the global batch.
 
-`SyntheticPointCloud` draws the batch from `diffudf_amd.synth` (uniform coordinates, the same three strata).
-The mesh-backed sampler (OBJ + point-to-triangle distance on the GPU) is the next row of the scope table
-(SURVEY.md §8(f) rank 1); the reference's own one needs open3d, which this image does not have.
+`SyntheticPointCloud` draws the batch from `diffudf_amd.synth` (uniform coordinates, the same three strata);
+`PointCloud` is the mesh-backed sampler: host-side OBJ/PLY preparation in
+`diffudf_amd/mesh.py`, per-step sampling + exact point-to-triangle distance on the GPU (`csrc/dudf_sample.hip`).
+The reference's own one needs open3d, which this image does not have.
 """
 import numpy as np
 import torch
@@ -53,10 +54,61 @@ class SyntheticPointCloud:
 
 
 class PointCloud:
-    """Reference constructor signature (reference src/dataset.py:135-155).  Mesh-backed sampling is not built
-    yet: constructing it says so instead of failing later on a missing open3d."""
+    """Mesh-backed batch source with the reference constructor (reference src/dataset.py:135-155):
+    `PointCloud(meshPath, batchSize, samplingPercentiles, batchesPerEpoch, device, onlyPCloud)`.
 
-    def __init__(self, meshPath, batchSize, samplingPercentiles, batchesPerEpoch, device=None, onlyPCloud=False):
-        raise NotImplementedError(
-            "PointCloud(mesh): the GPU surface sampler / point-to-triangle distance kernel is the next scope row "
-            "(SURVEY.md §8(f) rank 1); use SyntheticPointCloud or set \"dataset\": \"synthetic\" in the config")
+    `meshPath` is the reference's path prefix (`<prefix>_t.obj` + `<prefix>_pc.ply` as written by its preprocess.py);
+    when those do not exist `<prefix>.obj` is normalised and sampled in memory (diffudf_amd/mesh.py).  Every batch is
+    produced on the GPU by `dudf_sample_batch` and yielded as DEVICE tensors (the loop's `.to(device)` is then a
+    no-op), ordered [on | far | near] exactly like the reference.  `rank`/`world` shard each stratum.
+    `onlyPCloud=True` (point-cloud input, reference :80-131) is not built."""
+
+    def __init__(self, meshPath, batchSize, samplingPercentiles, batchesPerEpoch, device=None, onlyPCloud=False,
+                 seed=123, rank=0, world=1, surfacePoints=100000):
+        import ctypes
+        from . import _lib, mesh
+        if onlyPCloud:
+            raise NotImplementedError("PointCloud(onlyPCloud=True): the point-cloud-only sampler is not built")
+        self.device = torch.device("cuda", 0) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DudfError("PointCloud: the sampler runs on the GPU; there is no CPU fallback path")
+        tri, pos, nrm = mesh.prepare(meshPath, surfacePoints, seed)
+        self.tri = torch.from_numpy(tri).to(self.device)
+        self.pc_pos = torch.from_numpy(pos).to(self.device)
+        self.pc_nrm = torch.from_numpy(nrm).to(self.device)
+        self.batchSize, self.batchesPerEpoch = batchSize, batchesPerEpoch
+        self.samplesOnSurface = int(batchSize * samplingPercentiles[0])
+        self.samplesOffSurface = int(batchSize * samplingPercentiles[1])
+        self.n_far = self.samplesOffSurface // 2
+        self.n_near = self.samplesOffSurface - self.n_far
+        self.n_global = self.samplesOnSurface + self.samplesOffSurface
+        self.seed, self.rank, self.world = seed, rank, world
+        self._step = 0
+        self._lib, self._ct = _lib, ctypes
+
+    def n_local(self):
+        sl = lambda m: m * (self.rank + 1) // self.world - m * self.rank // self.world   # noqa: E731
+        return sl(self.samplesOnSurface), sl(self.n_far), sl(self.n_near)
+
+    def sample(self, step):
+        """(x (n,3), normals (n,3), sdf (n,)) device tensors for global step `step`; n_on leading on-surface points."""
+        ct, lib = self._ct, self._lib.load()
+        n_on, n_far, n_near = self.n_local()
+        n = n_on + n_far + n_near
+        x = torch.empty(n, 3, dtype=torch.float32, device=self.device)
+        nrm = torch.empty(n, 3, dtype=torch.float32, device=self.device)
+        sdf = torch.empty(n, dtype=torch.float32, device=self.device)
+        P = lambda t: ct.c_void_p(t.data_ptr())   # noqa: E731
+        with torch.cuda.device(self.device):
+            rc = lib.dudf_sample_batch(P(self.tri), self.tri.shape[0], P(self.pc_pos), P(self.pc_nrm),
+                                       self.pc_pos.shape[0], self.samplesOnSurface, self.n_far, self.n_near,
+                                       self.seed, step, self.rank, self.world, P(x), P(nrm), P(sdf),
+                                       ct.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self._lib.check(rc, "dudf_sample_batch")
+        return x, nrm, sdf
+
+    def __iter__(self):
+        for _ in range(self.batchesPerEpoch):
+            x, nrm, sdf = self.sample(self._step)
+            self._step += 1
+            yield x[None], nrm[None], sdf[None, :, None]

@@ -126,6 +126,16 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
 int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int channel, int64_t n, int64_t n_hess,
                           float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One training batch on the GPU — replaces `sampleTrainingData` (reference src/dataset.py:14-70, open3d on the CPU)
+ * for a triangle soup tri (n_tri,9) and its precomputed surface cloud pc_pos/pc_nrm (n_pc,3) (reference
+ * src/preprocess_mesh.py:39).  Writes THIS RANK's slice of the global batch [on | far | near] of
+ * n_on + n_far + n_near points: x (n_l,3), normals (n_l,3) (zero off-surface), sdf (n_l) (zero on-surface,
+ * unsigned distance otherwise); slice r of W of each stratum is [m*r/W, m*(r+1)/W).  Counter-based RNG keyed by
+ * (seed, step): the union over ranks does not depend on W. */
+int dudf_sample_batch(const float* tri, int64_t n_tri, const float* pc_pos, const float* pc_nrm, int64_t n_pc,
+                      int64_t n_on, int64_t n_far, int64_t n_near, uint64_t seed, uint64_t step, int rank, int world,
+                      float* x, float* normals, float* sdf, void* stream);
+
 /* Measurement hook (bench.py): while enabled, every kernel the library launches is bracketed by HIP
  * events ON THE STREAM IT IS LAUNCHED ON.  dudf_profile_dump synchronises those events and writes one
  * text line per kernel kind, "<name> <launches> <total_ms>\n", into buf (host), then clears the log. */

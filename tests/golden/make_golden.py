@@ -173,6 +173,44 @@ def main():
     out["grid_n"] = np.array(n); out["values"] = vals; out["gradients"] = grads; out["hessians"] = hess
     out["inv_tanh"] = inverse("tanh", np.abs(vals), 100)
     np.savez_compressed(os.path.join(HERE, "g4_query.npz"), **out)
+    # ---- G5: the reference's own example mesh (data/beetle), BASELINE config 0/1 -------------------------------
+    # batches from THIS repo's sampler restatement (oracle/sampler_oracle.py) on tests/golden/beetle.obj; the
+    # reference's loss_s1 + torch.optim.Adam run on exactly those batches gives the curve to follow.
+    from diffudf_amd import mesh
+    from oracle import sampler_oracle as SO
+    out = {}
+    hid = [256] * 8
+    p32 = synth.siren_params(hid, seed=123, dtype=np.float32)
+    n_theta = synth.flatten_params(p32).size
+    sample = np.arange(0, n_theta, 61)
+    tri, pos, nrm = mesh.prepare(os.path.join(HERE, "beetle"), 100000, seed=123)
+    bs, steps = 3000, 12
+    n_on, n_off = int(bs * 0.333), int(bs * 0.666)
+    n_far, n_near = n_off // 2, n_off - n_off // 2
+    batches = [SO.sample_batch(tri, pos, nrm, n_on, n_far, n_near, seed=123, step=t) for t in range(steps)]
+    for name, w in (("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])):
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            model = ref_model(hid, p32, dt)
+            opt = torch.optim.Adam(lr=1e-4, params=model.parameters())
+            hist = []
+            for t in range(steps):
+                x, nr, sd = [torch.from_numpy(a.astype(np.float64)).to(dt)[None] for a in batches[t]]
+                opt.zero_grad()
+                terms = loss_s1(model, x, {"normals": nr, "sdf": sd}, w, 100)
+                total = torch.zeros((1, 1), dtype=dt)
+                for v in terms.values():
+                    total = total + v
+                total.backward()
+                opt.step()
+                hist.append([float(v) for v in terms.values()])
+            theta = np.concatenate([p.detach().reshape(-1).double().numpy() for p in model.parameters()])
+            out[f"{name}_{tag}_hist"] = np.array(hist)
+            out[f"{name}_{tag}_theta_sample"] = theta[sample]
+    out["hidden"] = np.array(hid); out["sample"] = sample; out["param_seed"] = np.array(123)
+    out["batch_seed"] = np.array(123); out["batch_size"] = np.array(bs); out["steps"] = np.array(steps)
+    out["surface_points"] = np.array(100000)
+    out["batch0_x"] = batches[0][0]; out["batch0_sdf"] = batches[0][2]
+    np.savez_compressed(os.path.join(HERE, "g5_beetle.npz"), **out)
     print("golden fixtures written to", HERE)
 
 

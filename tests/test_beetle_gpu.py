@@ -1,0 +1,103 @@
+# coding: utf-8
+"""GPU: BASELINE config 0/1 — the reference's example mesh (data/beetle).  GPU batch sampler against its numpy
+restatement, and N training steps (sampler -> loss_s1 -> torch.optim.Adam) against the curve the REFERENCE produced
+on the same batches (tests/golden/g5_beetle.npz, made by tests/golden/make_golden.py)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from diffudf_amd import synth
+from oracle import sampler_oracle as SO
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+BEETLE = os.path.join(HERE, "golden", "beetle")
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_gpu_sampler_matches_oracle(golden_dir):
+    from diffudf_amd.dataset import PointCloud
+    G = np.load(os.path.join(golden_dir, "g5_beetle.npz"))
+    bs = int(G["batch_size"])
+    ds = PointCloud(BEETLE, bs, [0.333, 0.666], 1, device="cuda:0", seed=int(G["batch_seed"]))
+    assert ds.n_global == 2997 and ds.samplesOnSurface == 999
+    x, nrm, sdf = ds.sample(0)
+    # the batch the reference trajectory was generated on
+    assert np.abs(x.cpu().numpy() - G["batch0_x"]).max() < 1e-6
+    assert np.abs(sdf.cpu().numpy() - G["batch0_sdf"][:, 0]).max() < 2e-6
+    assert (sdf[:999] == 0).all() and (sdf[999:] > 0).all() and (nrm[999:] == 0).all()
+    # sharded: rank 1 of 3 produces exactly its slices, at a later step
+    ds3 = PointCloud(BEETLE, bs, [0.333, 0.666], 1, device="cuda:0", seed=7, rank=1, world=3)
+    tri, pos, pn = ds3.tri.cpu().numpy(), ds3.pc_pos.cpu().numpy(), ds3.pc_nrm.cpu().numpy()
+    xs, ns, ss = ds3.sample(5)
+    xo, no, so = SO.sample_batch(tri, pos, pn, 999, 999, 999, seed=7, step=5, rank=1, world=3)
+    assert np.abs(xs.cpu().numpy() - xo).max() < 1e-6 and np.array_equal(ns.cpu().numpy(), no)
+    assert np.abs(ss.cpu().numpy() - so[:, 0]).max() < 2e-6
+    # iterator contract of the reference dataset: (1,N,3), (1,N,3), (1,N,1)
+    a, b, c = next(iter(ds))
+    assert a.shape == (1, 2997, 3) and b.shape == (1, 2997, 3) and c.shape == (1, 2997, 1)
+
+
+@pytest.mark.parametrize("name,w", [("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])])
+def test_beetle_training_follows_reference(golden_dir, name, w):
+    """Loss after N steps on the beetle mesh within 1e-4 (relative) of the reference (north star); with the
+    eigenvector term on, the bar is the reference's own fp32-vs-fp64 drift (it is chaotic)."""
+    from src.dataset import PointCloud
+    from src.loss_functions import loss_s1
+    from src.model import SIREN
+    G = np.load(os.path.join(golden_dir, "g5_beetle.npz"))
+    hidden = list(G["hidden"])
+    model = SIREN(3, 1, hidden, w0=30)
+    sd = {}
+    for i, (wt, b) in enumerate(synth.siren_params(hidden, seed=int(G["param_seed"]))):
+        sd[f"net.{i}.0.weight"] = torch.from_numpy(wt); sd[f"net.{i}.0.bias"] = torch.from_numpy(b)
+    model.load_state_dict(sd)
+    model.to("cuda:0")
+    ds = PointCloud(BEETLE, int(G["batch_size"]), [0.333, 0.666], 1, device="cuda:0", seed=int(G["batch_seed"]))
+    opt = torch.optim.Adam(lr=1e-4, params=model.parameters())
+    hist = []
+    for t in range(int(G["steps"])):
+        for x, nrm, sdf in iter(ds):
+            opt.zero_grad()
+            loss = loss_s1(model, x, {"normals": nrm, "sdf": sdf}, w, 100)
+            total = torch.zeros((1, 1), device="cuda:0")
+            for l in loss.values():
+                total += l
+            total.backward()
+            opt.step()
+            hist.append([l.item() for l in loss.values()])
+    hist = np.array(hist)
+    ref = G[f"{name}_f64_hist"]
+    drift = np.abs(G[f"{name}_f32_hist"] - ref).max() / np.abs(ref).max()
+    per_step = np.abs(hist - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    et = rel(model.flat_parameters().cpu().numpy()[G["sample"]], G[f"{name}_f64_theta_sample"])
+    print(f"beetle {name}: per-step curve err {np.array2string(per_step, precision=1)}; theta err {et:.2e}; "
+          f"reference fp32 drift {drift:.2e}")
+    # Adam's first steps are sign-like (g / (|g| + 1e-8)): a parameter whose gradient sits below the fp32 noise floor
+    # (~1e-4 absolute here, the same for the reference's own fp32 run: tests/golden g2 f32-vs-f64) can take the other
+    # sign, which moves the NEXT loss by ~1e-6 relative and then grows chaotically.  Measured on MI355X: one such
+    # flip at step 0; <1e-4 through step 9; 1e-3 at step 11, while loss and gradient evaluated at IDENTICAL theta
+    # agree with fp64 to 1e-7 / 5e-7 (checked below and in test_hip_parity).  So: 1e-4 over the first 8 steps, and the
+    # whole curve within the larger of 5e-3 and twice the reference's own fp32 drift.
+    assert per_step[:8].max() < max(1e-4, 2.0 * drift)
+    assert per_step.max() < max(5e-3, 2.0 * drift)
+    # same-theta parity at the END of the run: HIP loss at the trained parameters vs the fp64 oracle at the same ones
+    from oracle import dudf_oracle as O
+    x, nrm, sdf = ds.sample(int(G["steps"]))
+    theta = model.flat_parameters().cpu().numpy().astype(np.float64)
+    P = synth.unflatten_params(theta, hidden)
+    xo, no, so = [t.cpu().numpy().astype(np.float64) for t in (x, nrm, sdf)]
+    t_ref, g_ref, _ = O.loss_and_grad("s1", P, xo, no, so.reshape(-1, 1), w, 100.0)
+    model.zero_grad()
+    loss = loss_s1(model, x[None], {"normals": nrm[None], "sdf": sdf[None, :, None]}, w, 100)
+    sum(loss.values()).backward()
+    got = np.array([l.item() for l in loss.values()])
+    assert rel(got, [float(v) for v in t_ref.values()]) < 1e-5
+    gh = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in model.parameters()])
+    gr = np.concatenate([np.concatenate([a.reshape(-1), b.reshape(-1)]) for a, b in g_ref])
+    assert rel(gh, gr) < (5e-4 if name == "s1full" else 1e-4)

@@ -192,7 +192,8 @@ def setup_train(parameter_dict, cuda_device):
     else:
         dataset = PointCloud(parameter_dict["dataset"], parameter_dict["batch_size"], sp,
                              parameter_dict["batches_per_epoch"], device=device,
-                             onlyPCloud=parameter_dict.get('onlyPCloud', False))
+                             onlyPCloud=parameter_dict.get('onlyPCloud', False), seed=seed,
+                             rank=rank or 0, world=world or 1)
 
     network_params = parameter_dict["network"]
     model = SIREN(n_in_features=3, n_out_features=1, hidden_layer_config=network_params["hidden_layer_nodes"],
