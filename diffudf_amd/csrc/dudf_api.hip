@@ -73,8 +73,9 @@ struct Ctx {
     float* ws;
 };
 
-int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, size_t bytes, void* stream, Ctx* c) {
-    int rc = dudf_make_layout(cfg, n, n_h, &c->lo);
+int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, size_t bytes, void* stream, Ctx* c,
+             int query_only = 0) {
+    int rc = dudf_make_layout(cfg, n, n_h, &c->lo, query_only);
     if (rc) return rc;
     if ((rc = check_ws(c->lo, workspace, bytes))) return rc;
     c->st = reinterpret_cast<hipStream_t>(stream);
@@ -82,13 +83,15 @@ int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, s
     return 0;
 }
 
-// pack + x4 + forward (+ reverse) sweeps with the given stash flags
-int forward_common(Ctx& c, const float* theta, const float* x, int store_s, int store_c, int train, bool reverse) {
+// pack + x4 + forward (+ reverse) sweeps with the given stash flags.  x == nullptr: x4 was already filled (grid query).
+// `train` = keep what the adjoint sweeps need; the forward sweep always runs its stash-everything variant (the only
+// one the register allocator handles without spills), queries merely skip the reverse sweep's stores.
+int forward_common(Ctx& c, const float* theta, const float* x, int train, bool reverse) {
     int rc;
     if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
-    if ((rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
+    if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
-    a.store_s = store_s; a.store_c = store_c; a.train = train;
+    a.store_s = 1; a.store_c = 1; a.train = train;
     if ((rc = run_sweep(SWEEP_FWD, c.lo, a, c.st))) return rc;
     if (reverse && (rc = run_sweep(SWEEP_REV, c.lo, a, c.st))) return rc;
     return 0;
@@ -131,6 +134,12 @@ size_t dudf_workspace_bytes(const dudf_net_cfg* cfg, int64_t n) {
     return lo.total_bytes;
 }
 
+size_t dudf_workspace_bytes_query(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess) {
+    DudfLayout lo;
+    if (dudf_make_layout(cfg, n, n_hess, &lo, 1)) return 0;
+    return lo.total_bytes;
+}
+
 size_t dudf_workspace_bytes_hess(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess) {
     DudfLayout lo;
     if (dudf_make_layout(cfg, n, n_hess, &lo)) return 0;
@@ -140,21 +149,48 @@ size_t dudf_workspace_bytes_hess(const dudf_net_cfg* cfg, int64_t n, int64_t n_h
 int dudf_query(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f, float* out_g,
                void* workspace, size_t workspace_bytes, void* stream) {
     Ctx c;
-    int rc = open_ctx(cfg, n, 0, workspace, workspace_bytes, stream, &c);
+    int rc = open_ctx(cfg, n, 0, workspace, workspace_bytes, stream, &c, 1);
     if (rc) return rc;
     if (n <= 0) return 0;
-    if ((rc = forward_common(c, theta, x, 0, out_g ? 1 : 0, 0, out_g != nullptr))) return rc;
+    if ((rc = forward_common(c, theta, x, 0, out_g != nullptr))) return rc;
     return dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, nullptr, c.st);
 }
 
 int dudf_query_hessian(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f,
                        float* out_g, float* out_h, void* workspace, size_t workspace_bytes, void* stream) {
     Ctx c;
-    int rc = open_ctx(cfg, n, n, workspace, workspace_bytes, stream, &c);
+    int rc = open_ctx(cfg, n, n, workspace, workspace_bytes, stream, &c, 1);
     if (rc) return rc;
     if (n <= 0) return 0;
-    if ((rc = forward_common(c, theta, x, 0, 1, 0, true))) return rc;
+    if ((rc = forward_common(c, theta, x, 0, true))) return rc;
     return dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, out_h, c.st);
+}
+
+int dudf_query_frame(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f,
+                     float* out_g, float* out_h, float* out_lambda, float* out_v, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    Ctx c;
+    int rc = open_ctx(cfg, n, n, workspace, workspace_bytes, stream, &c, 1);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if ((rc = forward_common(c, theta, x, 0, true))) return rc;
+    if ((rc = dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, out_h, c.st))) return rc;
+    return dudf_launch_field_features(c.lo, c.ws, 0, 1.0, nullptr, nullptr, nullptr, out_lambda, out_v, c.st);
+}
+
+int dudf_grid_fields(const dudf_net_cfg* cfg, const float* theta, int64_t grid_n, int64_t start, int64_t count,
+                     int inverse_mode, double alpha, float* out_df, float* out_vec, int* out_flag_count,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (grid_n < 2 || start < 0 || count < 0 || start + count > grid_n * grid_n * grid_n) return DUDF_E_BADCFG;
+    if (inverse_mode < 0 || inverse_mode > 2) return DUDF_E_BADMODE;
+    Ctx c;
+    int rc = open_ctx(cfg, count, 0, workspace, workspace_bytes, stream, &c, 1);
+    if (rc) return rc;
+    if (count == 0) return 0;
+    if ((rc = dudf_launch_make_x4_grid(c.lo, grid_n, start, c.ws, c.st))) return rc;
+    if ((rc = forward_common(c, theta, nullptr, 0, true))) return rc;
+    return dudf_launch_field_features(c.lo, c.ws, inverse_mode, alpha, out_df, out_vec, out_flag_count, nullptr,
+                                      nullptr, c.st);
 }
 
 int dudf_loss_forward(const dudf_net_cfg* cfg, int mode, const float* theta, const float* x, const float* normals,
@@ -165,7 +201,7 @@ int dudf_loss_forward(const dudf_net_cfg* cfg, int mode, const float* theta, con
     Ctx c;
     int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = forward_common(c, theta, x, 1, 1, 1, true))) return rc;
+    if ((rc = forward_common(c, theta, x, 1, true))) return rc;
     return dudf_launch_loss_fwd(c.lo, mode, normals, sdf, n_global, weights, alpha, c.ws, out_terms, c.st);
 }
 
@@ -174,7 +210,7 @@ int dudf_s2_forward_stats(const dudf_net_cfg* cfg, const float* theta, const flo
     Ctx c;
     int rc = open_ctx(cfg, n_local, 0, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = forward_common(c, theta, x, 1, 1, 1, false))) return rc;
+    if ((rc = forward_common(c, theta, x, 1, false))) return rc;
     return dudf_launch_s2_stats(c.lo, sdf, c.ws, stats, c.st);
 }
 
@@ -203,7 +239,7 @@ int dudf_fields_forward(const dudf_net_cfg* cfg, const float* theta, const float
     Ctx c;
     int rc = open_ctx(cfg, n, 0, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
-    if ((rc = forward_common(c, theta, x, 1, 1, 1, true))) return rc;
+    if ((rc = forward_common(c, theta, x, 1, true))) return rc;
     return dudf_launch_copy_out(c.lo, c.ws, out_f, out_g, nullptr, c.st);
 }
 

@@ -54,7 +54,7 @@ struct DudfLayout {
     size_t total_bytes;
 };
 
-static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo) {
+static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo, int query_only = 0) {
     if (!cfg || cfg->n_in != 3 || cfg->n_hidden_layers < 1) return DUDF_E_BADCFG;
     const int H = cfg->hidden, L = cfg->n_hidden_layers;
     if (!(H == 32 || H == 64 || H == 128 || H == 256)) return DUDF_E_BADCFG;
@@ -80,9 +80,14 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
     lo->stash_layer = (int64_t)H * lo->np;
     const int64_t stash = (int64_t)L * lo->stash_layer;
-    lo->ws_S = take(stash); lo->ws_C = take(stash); lo->ws_Q = take(stash);
-    lo->ws_R = take(stash); lo->ws_E = take(stash); lo->ws_A = take(stash); lo->ws_Z = take(stash);
+    lo->ws_S = take(stash); lo->ws_C = take(stash);
     lo->ws_ZS = n_h > 0 ? take(stash) : lo->ws_S;
+    if (query_only) {        // value / df/dx / Hessian queries only ever touch S, C, ZS: 16-24 KB per column instead of 56-64
+        lo->ws_Q = lo->ws_R = lo->ws_E = lo->ws_A = lo->ws_Z = lo->ws_S;
+    } else {
+        lo->ws_Q = take(stash); lo->ws_R = take(stash); lo->ws_E = take(stash); lo->ws_A = take(stash);
+        lo->ws_Z = take(stash);
+    }
     lo->ws_acc = take(2 * DUDF_NACC);
     lo->total_bytes = (size_t)o * sizeof(float);
     return 0;
@@ -111,6 +116,9 @@ int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st);
 int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStream_t st);
+int dudf_launch_make_x4_grid(const DudfLayout& lo, int64_t grid_n, int64_t start, float* ws, hipStream_t st);
+int dudf_launch_field_features(const DudfLayout& lo, const float* ws, int inverse_mode, double alpha, float* out_df,
+                               float* out_vec, int* out_flag_count, float* out_lam, float* out_V, hipStream_t st);
 int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, float* ws, float* out_terms, hipStream_t st);
 int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,

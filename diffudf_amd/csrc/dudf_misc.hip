@@ -386,6 +386,69 @@ __global__ __launch_bounds__(256) void copy_in_kernel(const float* __restrict__ 
     }
 }
 
+// x4 of a regular N^3 grid on [-1,1]^3, linear index start+c, first axis slowest — the sample order of reference
+// src/render_mc.py:36-49 (`extract_fields`); coordinates are index-derived, nothing is read from HBM.
+__global__ __launch_bounds__(256) void make_x4_grid_kernel(float* __restrict__ x4, int64_t n, int64_t np, int64_t N,
+                                                           int64_t start) {
+    const float voxel = 2.0f / (float)(N - 1);
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < np; c += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = {0, 0, 0, 0};
+        if (c < n) {
+            const int64_t i = start + c;
+            const int64_t i2 = i % N, i1 = (i / N) % N, i0 = (i / N / N) % N;
+            v = f32x4{(float)i0 * voxel - 1.0f, (float)i1 * voxel - 1.0f, (float)i2 * voxel - 1.0f, 1.f};
+        }
+        *reinterpret_cast<f32x4*>(x4 + c * 4) = v;
+    }
+}
+
+// Per-point features the renderers derive from (f, df/dx, Hessian):
+//   out_df  = inverse(gt_mode, |f|, alpha)                    reference src/inverses.py:3-21 via src/render_mc.py:71
+//   out_vec = -normalize(df/dx) (eps 1e-12)                    reference src/render_mc.py:74-75
+//   flags   : points whose NORMALISED gradient has norm < 0.04 (only a vanishing gradient does, :86-93): the caller
+//             re-queries those with the Hessian path for the eigenvector fallback
+//   out_lam / out_V (Hessian points): eigenvalues ascending and eigenvectors (columns) of the Hessian's lower triangle,
+//             reference src/render_st.py:57-62 `compute_normals_and_cd` (normal = V[:,2])
+__global__ __launch_bounds__(256) void field_features_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                             int64_t n, int64_t n_h, int64_t ncol_h, int inverse_mode,
+                                                             float alpha, float* __restrict__ out_df,
+                                                             float* __restrict__ out_vec, int* __restrict__ flag_count,
+                                                             float* __restrict__ out_lam, float* __restrict__ out_V) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = p < n_h ? 4 * p : ncol_h + (p - n_h);
+        if (out_df) {
+            const float f = fabsf(y[c]);
+            float d;
+            if (inverse_mode == 0) d = (f < 1.0f / alpha) ? sqrtf(f / alpha) : f;          // 'tanh'
+            else if (inverse_mode == 1) d = (f > 0.f) ? f : 0.01f;                        // 'siren' (min_step 0.01)
+            else d = ((f > 0.f) ? sqrtf(f) : 0.01f) / sqrtf(alpha);                       // 'squared'
+            out_df[p] = d;
+        }
+        if (out_vec) {
+            const float gx = g[c * 4], gy = g[c * 4 + 1], gz = g[c * 4 + 2];
+            const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+            const float inv = -1.0f / fmaxf(nrm, 1e-12f);
+            const float vx = gx * inv, vy = gy * inv, vz = gz * inv;
+            out_vec[p * 3] = vx; out_vec[p * 3 + 1] = vy; out_vec[p * 3 + 2] = vz;
+            if (flag_count && sqrtf(vx * vx + vy * vy + vz * vz) < 0.04f) atomicAdd(flag_count, 1);
+        }
+        if ((out_lam || out_V) && p < n_h) {
+            double Hm[3][3], lam[3], V[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Hm[0][k] = g[(c + 1 + k) * 4]; Hm[1][k] = g[(c + 1 + k) * 4 + 1]; Hm[2][k] = g[(c + 1 + k) * 4 + 2];
+            }
+            eigh3(Hm, lam, V);
+            if (out_lam) { out_lam[p * 3] = (float)lam[0]; out_lam[p * 3 + 1] = (float)lam[1]; out_lam[p * 3 + 2] = (float)lam[2]; }
+            if (out_V)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) out_V[p * 9 + i * 3 + j] = (float)V[i][j];
+        }
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -492,5 +555,24 @@ int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStre
     DudfProfScope prof(PROF_OTHER, st);
     hipLaunchKernelGGL(make_x4_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, x, ws + lo.ws_x4, lo.n, lo.n_h,
                        lo.ncol_h, lo.np);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_make_x4_grid(const DudfLayout& lo, int64_t grid_n, int64_t start, float* ws, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(make_x4_grid_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, ws + lo.ws_x4, lo.n, lo.np, grid_n,
+                       start);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_field_features(const DudfLayout& lo, const float* ws, int inverse_mode, double alpha, float* out_df,
+                               float* out_vec, int* out_flag_count, float* out_lam, float* out_V, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    if (out_flag_count) {
+        hipError_t e = hipMemsetAsync(out_flag_count, 0, sizeof(int), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(field_features_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, ws + lo.ws_g, lo.n,
+                       lo.n_h, lo.ncol_h, inverse_mode, (float)alpha, out_df, out_vec, out_flag_count, out_lam, out_V);
     return (int)hipGetLastError();
 }

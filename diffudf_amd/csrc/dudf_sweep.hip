@@ -476,7 +476,7 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
         case SWEEP_ADJ_REV:
             if (a.have_e) DUDF_GO(SWEEP_ADJ_REV, 1); else DUDF_GO(SWEEP_ADJ_REV, 0);
             break;
-        case SWEEP_FWD_H: if (a.train) DUDF_GO(SWEEP_FWD_H, 1); else DUDF_GO(SWEEP_FWD_H, 0); break;
+        case SWEEP_FWD_H: if (a.store_s) DUDF_GO(SWEEP_FWD_H, 1); else DUDF_GO(SWEEP_FWD_H, 0); break;
         case SWEEP_REV_H: if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0); break;
         case SWEEP_ADJ_FWD_H: DUDF_GO(SWEEP_ADJ_FWD_H, 0); break;
         case SWEEP_ADJ_REV_H: DUDF_GO(SWEEP_ADJ_REV_H, 0); break;

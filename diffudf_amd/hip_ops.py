@@ -55,7 +55,28 @@ class Workspace:
         assert self.buf.data_ptr() % 16 == 0
 
 
+class QueryWorkspace(Workspace):
+    """The smaller scratch the value / df/dx / Hessian queries need (no adjoint stash)."""
+
+    def __init__(self, cfg, n, device, n_hess=0):
+        self.cfg, self.n, self.n_hess = cfg, int(n), int(n_hess)
+        self.nbytes = int(_lib.load().dudf_workspace_bytes_query(ctypes.byref(cfg), self.n, self.n_hess))
+        if self.nbytes == 0:
+            _lib.check(-1, "dudf_workspace_bytes_query")
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+
+
 _ws_cache = {}
+_qws_cache = {}
+
+
+def query_workspace_for(cfg, n, device, n_hess=0):
+    key = (cfg.n_hidden_layers, cfg.hidden, cfg.w0, int(n), str(device), int(n_hess))
+    ws = _qws_cache.get(key)
+    if ws is None:
+        _qws_cache.clear()
+        ws = _qws_cache[key] = QueryWorkspace(cfg, n, device, n_hess)
+    return ws
 
 
 def workspace_for(cfg, n, device, n_hess=0):
@@ -74,7 +95,7 @@ def query(cfg, theta, x, want_grad=True, ws=None):
     x = _f32(x, "x").view(-1, 3)
     theta = _f32(theta, "theta")
     n = x.shape[0]
-    ws = ws or workspace_for(cfg, n, x.device)
+    ws = ws or query_workspace_for(cfg, n, x.device)
     f = torch.empty(n, dtype=torch.float32, device=x.device)
     g = torch.empty(n, 3, dtype=torch.float32, device=x.device) if want_grad else None
     rc = lib.dudf_query(ctypes.byref(cfg), _ptr(theta), _ptr(x), n, _ptr(f), _ptr(g), _ptr(ws.buf), ws.nbytes,
@@ -89,7 +110,7 @@ def query_hessian(cfg, theta, x, ws=None):
     x = _f32(x, "x").view(-1, 3)
     theta = _f32(theta, "theta")
     n = x.shape[0]
-    ws = ws or workspace_for(cfg, n, x.device, n_hess=n)
+    ws = ws or query_workspace_for(cfg, n, x.device, n_hess=n)
     f = torch.empty(n, dtype=torch.float32, device=x.device)
     g = torch.empty(n, 3, dtype=torch.float32, device=x.device)
     h = torch.empty(n, 3, 3, dtype=torch.float32, device=x.device)
@@ -97,6 +118,43 @@ def query_hessian(cfg, theta, x, ws=None):
                                 ws.nbytes, _stream())
     _lib.check(rc, "dudf_query_hessian")
     return f, g, h
+
+
+def query_frame(cfg, theta, x, ws=None):
+    """f, df/dx, Hessian, eigenvalues (n,3) ascending, eigenvectors (n,3,3) as columns — eigh of the Hessian's
+    lower triangle (reference src/render_st.py:57-62)."""
+    lib = _lib.load()
+    x = _f32(x, "x").view(-1, 3)
+    theta = _f32(theta, "theta")
+    n = x.shape[0]
+    ws = ws or query_workspace_for(cfg, n, x.device, n_hess=n)
+    dev = x.device
+    f = torch.empty(n, dtype=torch.float32, device=dev); g = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    h = torch.empty(n, 3, 3, dtype=torch.float32, device=dev); lam = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    v = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
+    rc = lib.dudf_query_frame(ctypes.byref(cfg), _ptr(theta), _ptr(x), n, _ptr(f), _ptr(g), _ptr(h), _ptr(lam), _ptr(v),
+                              _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_query_frame")
+    return f, g, h, lam, v
+
+
+INVERSE_MODES = {"tanh": 0, "siren": 1, "squared": 2}
+
+
+def grid_fields(cfg, theta, grid_n, start, count, gt_mode, alpha, out_df, out_vec, ws=None):
+    """Fills out_df[start:start+count], out_vec[start:start+count] (device tensors over the flattened N^3 grid);
+    returns the device int32 counter of points that need the Hessian-eigenvector fallback."""
+    lib = _lib.load()
+    theta = _f32(theta, "theta")
+    ws = ws or query_workspace_for(cfg, count, theta.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=theta.device)
+    df = out_df[start:start + count]
+    vec = out_vec[start:start + count]
+    rc = lib.dudf_grid_fields(ctypes.byref(cfg), _ptr(theta), int(grid_n), int(start), int(count),
+                              INVERSE_MODES[gt_mode], float(alpha), _ptr(df), _ptr(vec), _ptr(flag), _ptr(ws.buf),
+                              ws.nbytes, _stream())
+    _lib.check(rc, "dudf_grid_fields")
+    return flag
 
 
 def _w4(weights):

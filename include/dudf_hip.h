@@ -49,6 +49,9 @@ int64_t dudf_theta_count(const dudf_net_cfg* cfg);
  * the _hess form when the first n_hess of them take the Hessian path (4 columns each instead of 1) */
 size_t dudf_workspace_bytes(const dudf_net_cfg* cfg, int64_t n);
 size_t dudf_workspace_bytes_hess(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess);
+/* the smaller workspace that dudf_query / dudf_query_hessian / dudf_query_frame / dudf_grid_fields need
+ * (n_hess = n for the Hessian/frame queries, 0 otherwise) */
+size_t dudf_workspace_bytes_query(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess);
 
 /* Replaces `model(x)['model_out']` + `gradient(y, x)` as used by the chunk loop of
  * reference src/evaluate.py:26-35 (SIREN.forward src/model.py:116-135; gradient
@@ -63,6 +66,24 @@ int dudf_query(const dudf_net_cfg* cfg, const float* theta, const float* x, int6
 int dudf_query_hessian(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
                        float* out_f, float* out_g, float* out_h, void* workspace, size_t workspace_bytes,
                        void* stream);
+
+/* dudf_query_hessian plus the eigen-frame of the Hessian's lower triangle: out_lambda (n,3) ascending, out_v (n,3,3)
+ * eigenvectors as columns ([i][j] = component i of v_j; sign arbitrary) — `torch.linalg.eigh(hessian(y,x))` as used by
+ * reference src/render_st.py:57-62 `compute_normals_and_cd` (normal = v_2) and src/render_mc.py:77-78.  Any output
+ * pointer may be NULL. */
+int dudf_query_frame(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+                     float* out_f, float* out_g, float* out_h, float* out_lambda, float* out_v,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* The field part of `extract_fields` (reference src/render_mc.py:20-99) for grid points start .. start+count-1 of the
+ * regular grid_n^3 grid on [-1,1]^3 (linear index, first axis slowest, coordinates derived from the index):
+ * out_df (count) = inverse(gt_mode, |f|, alpha) with inverse_mode 0 'tanh' / 1 'siren' / 2 'squared'
+ * (src/inverses.py:3-21); out_vec (count,3) = -normalize(df/dx); *out_flag_count (device int) = number of points whose
+ * normalised gradient is shorter than 0.04 — the only ones for which the reference substitutes the sign-aligned top
+ * Hessian eigenvector (:80-93); the caller re-queries those with dudf_query_frame.  12 B in, 16 B out per point. */
+int dudf_grid_fields(const dudf_net_cfg* cfg, const float* theta, int64_t grid_n, int64_t start, int64_t count,
+                     int inverse_mode, double alpha, float* out_df, float* out_vec, int* out_flag_count,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Forward half of loss_s1 / loss_siren (reference src/loss_functions.py:123-155, :82-104):
  * SIREN forward, df/dx, the four weighted loss terms.  out_terms (device, 4 floats) receives

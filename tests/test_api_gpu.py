@@ -211,3 +211,29 @@ def test_train_cli_loop_runs(tmp_path):
     assert list(df.columns) == ["sdf_on_surf", "sdf_off_surf", "hessian_constraint", "grad_constraint", "std_on_surf"]
     assert len(df) == 6 and np.isfinite(df.values).all()
     assert (base / "params.json").exists()
+
+
+def test_extract_fields_and_frames(golden_dir):
+    """reference src/render_mc.py:20-99 field part and src/render_st.py:57-62, against the fixture made by the
+    reference's evaluate() + its inverse(), with the reference's own epilogue restated in numpy."""
+    from src.render_mc import extract_fields
+    from src.render_st import compute_normals_and_cd
+    model, P = make_model([256] * 8, 123)
+    G = np.load(os.path.join(golden_dir, "g4_query.npz"))
+    n = int(G["grid_n"])
+    df, vecs = extract_fields(model, None, n, "tanh", torch.device("cuda:0"), 100, chunk=700)
+    assert df.shape == (n, n, n) and vecs.shape == (n, n, n, 3) and df.dtype == torch.float32
+    assert np.allclose(df.cpu().numpy().reshape(-1), G["inv_tanh"][:, 0], rtol=2e-5, atol=1e-7)
+    g = G["gradients"]
+    ref_vec = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-12)
+    assert np.abs(vecs.cpu().numpy().reshape(-1, 3) - ref_vec).max() < 1e-4
+    # eigen-frame at arbitrary points: normals = top eigenvector of the reference's Hessians (sign-free)
+    ax = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    out = model(torch.from_numpy(grid)[None].cuda())
+    normals, cd = compute_normals_and_cd(out["model_in"], out["model_out"])
+    assert normals.shape == (1, n ** 3, 3) and cd.shape == (1, n ** 3, 3, 2)
+    lam, V = np.linalg.eigh(G["hessians"])
+    cosang = np.abs((normals[0].cpu().numpy() * V[:, :, 2]).sum(-1))
+    gap = lam[:, 2] - lam[:, 1]
+    assert cosang[gap > 1e-2 * np.abs(lam).max()].min() > 1 - 1e-4
