@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Secondary measurements (not the headline metric): inference-side queries of BASELINE configs 4 and 5.
+
+    python bench_query.py [--grid 256] [--rays 512]
+
+config 5: `extract_fields` field part on a grid^3 grid (value + df/dx + inverse map + normalisation), points/s;
+config 4: value + df/dx + Hessian + eigen-frame on rays^2 points, points/s.  One JSON line each."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--rays", type=int, default=512)
+    args = ap.parse_args()
+    from diffudf_amd import hip_ops, synth
+    from diffudf_amd.model import SIREN
+    from diffudf_amd.render_mc import extract_fields
+    hidden = [256] * 8
+    model = SIREN(3, 1, hidden)
+    sd = {}
+    for i, (w, b) in enumerate(synth.siren_params(hidden, seed=123)):
+        sd[f"net.{i}.0.weight"] = torch.from_numpy(w); sd[f"net.{i}.0.bias"] = torch.from_numpy(b)
+    model.load_state_dict(sd)
+    model.to("cuda:0")
+    F0 = 2 * (3 * 256 + 7 * 256 * 256 + 256)
+    N = args.grid
+    extract_fields(model, None, 64, "tanh", "cuda:0", 100)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    df, vecs = extract_fields(model, None, N, "tanh", "cuda:0", 100)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "grid field query points/sec (value + df/dx + inv_tanh + normalise)", "value": N ** 3 / dt,
+                      "unit": "points/s", "grid": N, "seconds": dt, "tflops_fp32_mfma": 2 * F0 * N ** 3 / dt / 1e12,
+                      "config": "BASELINE configs[4]: src/render_mc.py extract_fields field part"}))
+    M = args.rays ** 2
+    x = torch.from_numpy(synth.training_batch(M, seed=5)[0]).cuda()
+    cfg = model.hip_cfg
+    hip_ops.query_frame(cfg, model.flat_parameters(), x[:4096])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = hip_ops.query_frame(cfg, model.flat_parameters(), x)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "Hessian frame query points/sec (value + df/dx + Hessian + eigh)", "value": M / dt,
+                      "unit": "points/s", "points": M, "seconds": dt, "tflops_fp32_mfma": 8 * F0 * M / dt / 1e12,
+                      "config": "BASELINE configs[3]: analytic d2f/dx2 kernel on 512^2 ray points"}))
+
+
+if __name__ == "__main__":
+    main()
