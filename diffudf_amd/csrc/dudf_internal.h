@@ -113,6 +113,7 @@ enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,
        SWEEP_FWD_H = 4, SWEEP_REV_H = 5, SWEEP_ADJ_FWD_H = 6, SWEEP_ADJ_REV_H = 7 };   // Hessian-quad variants
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
+
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st);
 int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStream_t st);

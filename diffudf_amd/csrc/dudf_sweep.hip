@@ -265,12 +265,15 @@ struct Pending {
     int64_t ub0, ub1;
 };
 
-template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
+// One sweep over one 64-column tile.  `seed` replaces the per-column operand the prologue would read from HBM when
+// the caller already has it in registers (fused step kernel: gbar[q] for SWEEP_ADJ_FWD, ybar for SWEEP_ADJ_REV);
+// `res` returns what the tail produced: y in [0] (SWEEP_FWD, every lane), the a_0 rows in [0..2] (SWEEP_REV, lanes < 16).
+template <int H, int SW, int FL, bool SEEDED = false>
+__device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, float* lds, unsigned& gc, float seed,
+                                           f32x4& res) {
     using G = Geo<H>;
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const bool isv = !HS || (lane & 3) == 0;           // value channel (always, on the plain path)
@@ -279,9 +282,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
 
     f32x4 in[G::NT], nxt[G::NT];
     f32x4 stg[G::NSTG];
-    unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
-
-    for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x) {
+    {
         const int64_t p = (int64_t)tile * TILE + wave * 16 + li;        // this lane's column
         // j-th hidden matrix this sweep multiplies by, and the 0-based layer index its output belongs to
         auto matrix = [&](int j) -> const float* {
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
         {
             float b = 0.f, yb = 1.f;
             if constexpr (BS == SWEEP_FWD) b = a.x4[p * 4 + q];                       // (x,1) | (e_k,0): k=3 carries the bias
-            if constexpr (BS == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f; // A_0 = gbar | Hbar columns
-            if constexpr (BS == SWEEP_ADJ_REV) yb = a.ybar[p];
+            if constexpr (BS == SWEEP_ADJ_FWD) b = SEEDED ? seed : ((q < 3) ? a.gbar[p * 4 + q] : 0.f);   // A_0 = gbar | Hbar columns
+            if constexpr (BS == SWEEP_ADJ_REV) yb = SEEDED ? seed : a.ybar[p];
             if constexpr (SW == SWEEP_REV_H) yb = isv ? 1.f : 0.f;                    // adot_L^k = 0
             const int l0 = kFwdDir ? 0 : a.L - 1;
 #pragma unroll
@@ -390,11 +391,19 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
                     if (r == 0) { in[G::NT - 2] = e0; in[G::NT - 1] = e1; }
                     else { nxt[2 * r - 2] = e0; nxt[2 * r - 1] = e1; }
                 };
+                // A operands are fetched one k-tile ahead of the MFMAs that consume them (LDS latency, doubled by the
+                // 2-way bank conflict of the padded rows, stays behind 8 MFMAs instead of stalling every k-tile)
+                f32x4 a0n = *reinterpret_cast<const f32x4*>(bp);
+                f32x4 a1n = *reinterpret_cast<const f32x4*>(bp + 16 * G::LDW);
 #pragma unroll
                 for (int T = 0; T < G::NT; ++T) {
                     if (G::NT <= 2 && T == 0) chunk_head();     // tiny nets: k-tile 0 itself is one of the pending tiles
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(bp + 16 * T);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(bp + 16 * G::LDW + 16 * T);
+                    const f32x4 a0 = a0n, a1 = a1n;
+                    if (T + 1 < G::NT) {
+                        a0n = *reinterpret_cast<const f32x4*>(bp + 16 * (T + 1));
+                        a1n = *reinterpret_cast<const f32x4*>(bp + 16 * G::LDW + 16 * (T + 1));
+                        __builtin_amdgcn_sched_barrier(0x7F);   // everything but LDS ops may cross: the reads stay early
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         cur.acc0 = mfma16(a0[t], in[T][t], cur.acc0);
@@ -428,7 +437,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
             }
             part += __shfl_xor(part, 16);               // the 4 lane quarters hold disjoint feature rows
             part += __shfl_xor(part, 32);
-            if (q == 0) a.y[p] = part + a.theta[a.off_bo];
+            part += a.theta[a.off_bo];
+            if (q == 0) a.y[p] = part;
+            res[0] = part;
         } else if constexpr (BS == SWEEP_REV) {         // a_0 = W_1^T q_1 (rows 0..2 of a 16-row tile): df/dx | Hessian column
             f32x4 accg = {0, 0, 0, 0};
 #pragma unroll
@@ -438,8 +449,18 @@ __global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
                 for (int t = 0; t < 4; ++t) accg = mfma16(w[t], in[T][t], accg);
             }
             if (q == 0) *reinterpret_cast<f32x4*>(a.g + p * 4) = f32x4{accg[0], accg[1], accg[2], 0.f};
+            res = accg;
         }
     }
+}
+
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
+    f32x4 res;
+    for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x)
+        sweep_tile<H, SW, FL>(a, tile, lds, gc, 0.f, res);
 }
 
 template <int H>
@@ -463,11 +484,9 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((sweep_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);              \
     } while (0)
     switch (which) {
-        case SWEEP_FWD:
-            if (a.store_s && a.store_c) DUDF_GO(SWEEP_FWD, 3);
-            else if (a.store_c) DUDF_GO(SWEEP_FWD, 2);
-            else if (!a.store_s) DUDF_GO(SWEEP_FWD, 0);
-            else return DUDF_E_BADMODE;
+        case SWEEP_FWD:                                  // the stash-everything variant is the only one built: the
+            if (!(a.store_s && a.store_c)) return DUDF_E_BADMODE;   // leaner ones made the register allocator spill
+            DUDF_GO(SWEEP_FWD, 3);
             break;
         case SWEEP_REV:
             if (a.train) DUDF_GO(SWEEP_REV, 1); else DUDF_GO(SWEEP_REV, 0);
@@ -476,7 +495,7 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
         case SWEEP_ADJ_REV:
             if (a.have_e) DUDF_GO(SWEEP_ADJ_REV, 1); else DUDF_GO(SWEEP_ADJ_REV, 0);
             break;
-        case SWEEP_FWD_H: if (a.store_s) DUDF_GO(SWEEP_FWD_H, 1); else DUDF_GO(SWEEP_FWD_H, 0); break;
+        case SWEEP_FWD_H: if (!a.store_s) return DUDF_E_BADMODE; DUDF_GO(SWEEP_FWD_H, 1); break;
         case SWEEP_REV_H: if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0); break;
         case SWEEP_ADJ_FWD_H: DUDF_GO(SWEEP_ADJ_FWD_H, 0); break;
         case SWEEP_ADJ_REV_H: DUDF_GO(SWEEP_ADJ_REV_H, 0); break;

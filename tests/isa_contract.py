@@ -19,7 +19,7 @@ def emit_asm(src, out):
 def analyse(asm_path):
     txt = open(asm_path).read()
     out = {}
-    for m in re.finditer(r"^(_ZN\w*sweep_kernelILi256ELi(\d)ELi(\d)E\w*):[^\n]*$", txt, re.M):
+    for m in re.finditer(r"^(_ZN\w*(?:sweep_kernelILi256ELi(\d)ELi(\d)E|step_kernelILi256ELi(\d)E)\w*):[^\n]*$", txt, re.M):
         end = txt.index("s_endpgm", m.end())
         body = txt[m.end():end]
         pairs, drains, cnt, scratch, in_asm = [], [], None, 0, False
@@ -43,10 +43,11 @@ def analyse(asm_path):
                     cnt = None
                 else:                            # compiler wait while a DMA is in flight: legal, may drain it early
                     drains.append((cnt, n))
-        out[(int(m.group(2)), int(m.group(3)))] = {"pairs": pairs, "drains": drains, "scratch": scratch}
+        key = (int(m.group(2)), int(m.group(3))) if m.group(2) is not None else ("step", int(m.group(4)))
+        out[key] = {"pairs": pairs, "drains": drains, "scratch": scratch}
     return out
 
 
 if __name__ == "__main__":
-    for k, v in sorted(analyse(sys.argv[1]).items()):
+    for k, v in sorted(analyse(sys.argv[1]).items(), key=str):
         print(k, v["scratch"], v["pairs"], "drains:", v["drains"])
