@@ -17,6 +17,7 @@
 // (every column on the plain range, channel 0 of each quad on the Hessian range; padding columns hold zeros).
 // The two thin layers (3 inputs / 1 output) are a bandwidth-bound VALU reduction.
 #include "dudf_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -175,6 +176,199 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     }
 }
 
+// ---- the same GEMM on the bf16 matrix cores, at fp32 accuracy ("bf16x6") ---------------------------------------------
+// Every fp32 operand is split EXACTLY into three bf16 pieces v = h + m + l (8+8+8 significand bits); a product a*b is
+// the six piece products with combined order <= 2 (hh, hm, mh, hl, lh, mm), each exact in the MFMA and accumulated in
+// fp32; the dropped ones (ml, lm, ll) are <= 2^-24 relative, the size of one fp32 rounding.  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles, K = 2) per 16 points:
+// 2.67x less matrix-pipe time for the same 183 GFLOP.  The split (5.5 VALU ops per element, only of the fragments a
+// wave consumes) runs beside the MFMAs.  tests/test_hip_parity.py holds the result to the SAME tolerances as fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct Split3 { bf16x8 h, m, l; };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk(f32x2 v) {              // one v_cvt_pk_bf16_f32: lo = bf16(v.x), hi = bf16(v.y)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 unpack(unsigned p) {              // the two bf16 back as exact floats
+    return f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+}
+
+// 8 consecutive columns c0..c0+7 of one feature out of the swizzled [fq][16][4] image (column c sits at slot c ^ swz)
+// -> three bf16 fragments, worked on as packed pairs (3 cvt_pk + 4 bit ops + 2 packed subtracts per pair), + the
+// masked row sum for the bias gradient
+__device__ __forceinline__ Split3 load_split_swz(const float* row, int c0, int swz, float& sum, float f_other) {
+    u32x4 hp, mp, lp;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {row[((c0 + 2 * i) ^ swz) * 4], row[((c0 + 2 * i + 1) ^ swz) * 4]};
+        const unsigned h = cvt_pk(v);
+        const f32x2 r1 = v - unpack(h);
+        const unsigned m = cvt_pk(r1);
+        const f32x2 r2 = r1 - unpack(m);
+        hp[i] = h; mp[i] = m; lp[i] = cvt_pk(r2);
+        acc += ((i & 1) == 0 ? v.x : v.x * f_other) + v.y * f_other;     // Hessian range: only columns % 4 == 0 count
+    }
+    sum = acc;
+    Split3 r;
+    r.h = __builtin_bit_cast(bf16x8, hp); r.m = __builtin_bit_cast(bf16x8, mp); r.l = __builtin_bit_cast(bf16x8, lp);
+    return r;
+}
+
+// Staging for this kernel: LDS-DMA (inline asm, see dudf_sweep.hip for why) into a 4-deep ring of 16-column stages.
+// The image of one operand is [feature quad][16 columns][4 features] WITHOUT padding (a DMA wave-instruction writes
+// 1 KiB linearly); bank conflicts of the per-feature b32 reads are removed by storing column c of quad fq at slot
+// c ^ (fq & 7) — applied through the per-lane SOURCE address of the DMA and again on the read.  Three stages are in
+// flight behind a counted vmcnt, because at bf16 rates a stage is consumed in ~1.5 us — less than an HBM round trip.
+constexpr int KB = 16;          // columns per stage of the bf16 kernel
+constexpr int NRING = 4;
+
+template <int H>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_kernel(WgradArgs a) {
+    using W = WG<H>;
+    constexpr int NW_ = W::WO * W::WI;
+    constexpr int FQ = H / 4;
+    constexpr int OPER = FQ * KB * 4;                       // floats per operand image
+    constexpr int STAGE = 2 * OPER;                         // X image | Y image
+    constexpr int PIECES = (FQ * KB) / 64;                  // 1 KiB DMA pieces per operand image
+    static_assert(PIECES % NW_ == 0, "every wave stages the same number of pieces");
+    constexpr int PPW = PIECES / NW_;                       // pieces per wave and operand
+    constexpr int PER_WAVE = 2 * PPW;                       // DMA instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [NRING][X image | Y image]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / W::WI, wi = wave % W::WI;
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int j = blockIdx.x;
+    const int nsplit = gridDim.y;
+    const int steps16 = a.steps_total * (KT / KB);
+    const int s0 = (int)((int64_t)steps16 * blockIdx.y / nsplit);
+    const int s1 = (int)((int64_t)steps16 * (blockIdx.y + 1) / nsplit);
+
+    f32x16 acc[W::MT][W::NTL];
+    float bsum[W::MT];
+#pragma unroll
+    for (int m = 0; m < W::MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < W::NTL; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+        bsum[m] = 0.f;
+    }
+    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer;
+    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer;
+    const float* Y0 = a.A + (int64_t)j * a.stash_layer;
+    const float* Y1 = a.S + (int64_t)j * a.stash_layer;
+
+    const int npair = a.have_g ? 2 : 1;
+    const int nit = npair * (s1 - s0);
+    auto pair_of = [&](int it) { return a.have_g ? (it & 1) : 1; };
+    auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
+
+    // lane part of the DMA source: granule (fq_in_piece = lane/16, slot = lane%16) holds column slot ^ (fq & 7)
+    auto issue = [&](int it) {
+        const int pair = pair_of(it);
+        const int64_t col0 = (int64_t)step_of(it) * KB;
+        float* ring = lds + (it % NRING) * STAGE;
+        const float* xs = pair ? X1 : X0;
+        const float* ys = pair ? Y1 : Y0;
+#pragma unroll
+        for (int oper = 0; oper < 2; ++oper) {
+#pragma unroll
+            for (int v = 0; v < PPW; ++v) {
+                const int piece = wave + NW_ * v;           // wave-uniform 1 KiB piece of this operand's image
+                const int fq = piece * 4 + (lane >> 4);
+                const int col = (lane & 15) ^ (fq & 7);
+                const float* src = (oper ? ys : xs) + ((int64_t)fq * a.np + col0 + col) * 4;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) float*)(ring + oper * OPER + piece * 256));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        }
+    };
+    // prologue: three stages in flight
+    for (int it = 0; it < NRING - 1 && it < nit; ++it) issue(it);
+    if (nit > 0) {
+        if (nit >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        // the ring slot of stage it+3 was read in iteration it-1; every wave is past that iteration's barrier
+        if (it + NRING - 1 < nit) issue(it + NRING - 1);
+        const float* buf = lds + (it % NRING) * STAGE;
+        const float bflag = (pair_of(it) == 1 && wi == 0) ? 1.f : 0.f;
+        const bool hstage = (int64_t)step_of(it) * KB < a.ncol_h;
+        const float f_other = hstage ? 0.f : 1.f;
+        const int c0 = 8 * hh;                                    // MFMA k = 8*(lane>>5) + jj -> column c0 + jj
+        Split3 af[W::MT];
+#pragma unroll
+        for (int m = 0; m < W::MT; ++m) {
+            const int feat = (wo * W::MT + m) * 32 + l32;
+            float rs;
+            af[m] = load_split_swz(buf + (feat >> 2) * (KB * 4) + (feat & 3), c0, (feat >> 2) & 7, rs, f_other);
+            bsum[m] = fmaf(rs, bflag, bsum[m]);
+        }
+#pragma unroll
+        for (int n = 0; n < W::NTL; ++n) {
+            const int feat = (wi * W::NTL + n) * 32 + l32;
+            float dummy;
+            const Split3 bf = load_split_swz(buf + OPER + (feat >> 2) * (KB * 4) + (feat & 3), c0, (feat >> 2) & 7,
+                                             dummy, 1.f);
+#pragma unroll
+            for (int m = 0; m < W::MT; ++m) {
+                f32x16 c = acc[m][n];
+                c = mfma_bf16(af[m].m, bf.m, c);              // smallest terms first
+                c = mfma_bf16(af[m].l, bf.h, c);
+                c = mfma_bf16(af[m].h, bf.l, c);
+                c = mfma_bf16(af[m].m, bf.h, c);
+                c = mfma_bf16(af[m].h, bf.m, c);
+                c = mfma_bf16(af[m].h, bf.h, c);
+                acc[m][n] = c;
+            }
+        }
+        // stage it+1 has landed: all but the DMA pieces of the (up to) two younger stages are retired
+        if (it + 1 < nit) {
+            if (it + 3 < nit) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER_WAVE) : "memory");
+            else if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+
+    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride;
+    float* dB = dW + (int64_t)H * H;
+    if (nit > 0) {
+#pragma unroll
+        for (int m = 0; m < W::MT; ++m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int o = (wo * W::MT + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+                for (int n = 0; n < W::NTL; ++n) {
+                    const int i = (wi * W::NTL + n) * 32 + l32;
+                    atomicAdd(dW + (int64_t)o * H + i, acc[m][n][e]);
+                }
+            }
+            const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (wi == 0 && hh == 0) atomicAdd(dB + (wo * W::MT + m) * 32 + l32, tot);
+        }
+    }
+}
+
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
 //   dW_1[o][d] | db_1[o] = sum_c  q_1[o][c] * gbar[c][d]  +  zbar_1[o][c] * x4[c][d]      (d = 3 is the bias: x4[c][3])
 //   dW_out[f]            = sum_c  A_L[f][c] * x4[c][3]   +  ybar[c] * s_L[f][c]
@@ -255,6 +449,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     using W = WG<H>;
     constexpr int NTHR = 64 * W::WO * W::WI;
     const size_t smem = 4 * (size_t)(H / 4) * KTP * 4 * sizeof(float);   // 2 buffers x (X tile + Y tile)
+    const size_t smem_bf = (size_t)NRING * 2 * (H / 4) * KB * 4 * sizeof(float);   // ring of 4 x (X image + Y image)
     const int nl = a.L - 1;
     if (nl <= 0) return 0;
     int nsplit = 256 / nl;                               // one resident workgroup per CU, a single round
@@ -267,7 +462,20 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit), dim3(NTHR), smem, st, a);
+    // DUDF_WGRAD=f32 selects the f32-input MFMA kernel (A/B testing); default: bf16x6 at fp32 accuracy
+    static const bool use_f32 = [] { const char* e = getenv("DUDF_WGRAD"); return e && e[0] == 'f'; }();
+    if (use_f32) {
+        hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit), dim3(NTHR), smem, st, a);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_bf16_kernel<H>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bf);
+            if (e != hipSuccess) return (int)e;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit), dim3(NTHR), smem_bf, st, a);
+    }
     return (int)hipGetLastError();
 }
 
