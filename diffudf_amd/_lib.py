@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdudf_hip.so")
 LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
 
 _ERRORS = {
-    -1: "DUDF_E_BADCFG: unsupported network (equal hidden widths in {32,64,128,256}, n_in=3, n_out=1)",
+    -1: "DUDF_E_BADCFG: unsupported network (equal hidden widths in {32,64,128,256,512}, n_in=3, n_out=1)",
     -2: "DUDF_E_WORKSPACE: workspace too small or misaligned",
     -3: "DUDF_E_BADMODE",
     -4: "DUDF_E_UNSUPPORTED: this configuration has no HIP path; there is deliberately no CPU fallback",

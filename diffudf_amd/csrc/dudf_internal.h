@@ -57,7 +57,7 @@ struct DudfLayout {
 static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo, int query_only = 0) {
     if (!cfg || cfg->n_in != 3 || cfg->n_hidden_layers < 1) return DUDF_E_BADCFG;
     const int H = cfg->hidden, L = cfg->n_hidden_layers;
-    if (!(H == 32 || H == 64 || H == 128 || H == 256)) return DUDF_E_BADCFG;
+    if (!(H == 32 || H == 64 || H == 128 || H == 256 || H == 512)) return DUDF_E_BADCFG;
     if (n < 0 || n_h < 0 || n_h > n) return DUDF_E_BADCFG;
     lo->H = H; lo->L = L; lo->w0 = cfg->w0;
     lo->n = n; lo->n_h = n_h;

@@ -36,7 +36,8 @@ struct Geo {
     static constexpr int BUF = 32 * LDW;          // floats per LDS chunk buffer
     static constexpr int NTHR = 64 * NW;
     static constexpr int F4 = 8 * H;              // float4 per chunk
-    static constexpr bool DMA = (H == 256);       // one LDS-DMA wave-instruction == one 1 KiB weight row
+    static constexpr bool DMA = (H % 256 == 0);   // an LDS-DMA wave-instruction moves 1 KiB = a weight row (or half of one)
+    static constexpr int WPSIMD = (H > 256) ? 1 : 2;   // H = 512: 2 x 128 activation registers -> one wave per SIMD
     static constexpr int NSTG = DMA ? 1 : (F4 + NTHR - 1) / NTHR;
 };
 
@@ -57,15 +58,16 @@ __device__ __forceinline__ void stage_issue(const float* __restrict__ M, int r, 
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-        for (int i = 0; i < 32 / NW; ++i) {
-            const int row = wave * (32 / NW) + i;
-            const float* g = M + (size_t)(32 * r + row) * H + lane * 4;
+        for (int i = 0; i < (32 / NW) * (H / 256); ++i) {
+            const int row = wave * (32 / NW) + i / (H / 256);
+            const int part = i % (H / 256);                  // 1 KiB piece of the row
+            const float* g = M + (size_t)(32 * r + row) * H + part * 256 + lane * 4;
             // LDS byte address of the row, wave-uniform -> M0.  Inline asm on purpose: a builtin LDS-DMA makes
             // hipcc wait vmcnt(0) before the next ds_read of ANY LDS address (it cannot prove the two chunk
             // buffers distinct), which would expose the whole DMA latency at every chunk.  The matching wait is
             // dma_wait() in front of the chunk barrier.
             const unsigned l = __builtin_amdgcn_readfirstlane(
-                (unsigned)(size_t)(__attribute__((address_space(3))) float*)(buf + row * G::LDW));
+                (unsigned)(size_t)(__attribute__((address_space(3))) float*)(buf + row * G::LDW + part * 256));
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                          "s_mov_b32 m0, %0"
@@ -455,7 +457,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
 }
 
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NW, 2) void sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(64 * NW, Geo<H>::WPSIMD) void sweep_kernel(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
     f32x4 res;
@@ -469,7 +471,8 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
     const size_t smem = 2 * G::BUF * sizeof(float);
     const int ntiles = a.ntiles;
     if (ntiles <= 0) return 0;
-    int grid = ntiles < 512 ? ntiles : 512;            // two 4-wave workgroups per CU
+    const int slots = 256 * G::WPSIMD;                 // resident 4-wave workgroups: two per CU (one for H = 512)
+    int grid = ntiles < slots ? ntiles : slots;
     if (grid < 1) grid = 1;
     hipError_t e = hipSuccess;
 #define DUDF_GO(SW, FL)                                                                                     \
@@ -495,10 +498,21 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
         case SWEEP_ADJ_REV:
             if (a.have_e) DUDF_GO(SWEEP_ADJ_REV, 1); else DUDF_GO(SWEEP_ADJ_REV, 0);
             break;
-        case SWEEP_FWD_H: if (!a.store_s) return DUDF_E_BADMODE; DUDF_GO(SWEEP_FWD_H, 1); break;
-        case SWEEP_REV_H: if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0); break;
-        case SWEEP_ADJ_FWD_H: DUDF_GO(SWEEP_ADJ_FWD_H, 0); break;
-        case SWEEP_ADJ_REV_H: DUDF_GO(SWEEP_ADJ_REV_H, 0); break;
+        // Hessian-quad variants: not built for H = 512 (hipcc 7.2 emits illegal AGPR operands for them at 512 registers)
+        case SWEEP_FWD_H:
+            if constexpr (H > 256) return DUDF_E_UNSUPPORTED;
+            else { if (!a.store_s) return DUDF_E_BADMODE; DUDF_GO(SWEEP_FWD_H, 1); }
+            break;
+        case SWEEP_REV_H:
+            if constexpr (H > 256) return DUDF_E_UNSUPPORTED;
+            else { if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0); }
+            break;
+        case SWEEP_ADJ_FWD_H:
+            if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_ADJ_FWD_H, 0);
+            break;
+        case SWEEP_ADJ_REV_H:
+            if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_ADJ_REV_H, 0);
+            break;
         default: return DUDF_E_BADMODE;
     }
 #undef DUDF_GO
@@ -515,6 +529,7 @@ int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st) {
         case 64: return launch_h<64>(which, a, st);
         case 128: return launch_h<128>(which, a, st);
         case 256: return launch_h<256>(which, a, st);
+        case 512: return launch_h<512>(which, a, st);
         default: return DUDF_E_BADCFG;
     }
 }

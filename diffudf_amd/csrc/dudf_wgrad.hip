@@ -38,6 +38,8 @@ struct WgradArgs {
     int steps_total;                    // np / KT
     int L;
     int have_g;                         // 0: loss without df/dx terms (loss_s2) -> only the zbar*s pair
+    int Hs;                             // real layer width; the kernels' template H is the output TILE (<= 256):
+                                        // blockIdx.z walks the (Hs/H)^2 tiles of a wider layer
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     const int nsplit = gridDim.y;
     const int s0 = (int)((int64_t)a.steps_total * blockIdx.y / nsplit);
     const int s1 = (int)((int64_t)a.steps_total * (blockIdx.y + 1) / nsplit);
+    const int tz = a.Hs / H;                        // output tiles per side
+    const int o_off = (blockIdx.z / tz) * H, i_off = (blockIdx.z % tz) * H;
+    const int64_t xrow = (int64_t)(o_off / 4) * a.np * 4, yrow = (int64_t)(i_off / 4) * a.np * 4;
 
     f32x16 acc[W::MT][W::NTL];
     float bsum[W::MT];                              // bias gradient: running row sums of zbar (VALU, beside the MFMAs)
@@ -74,10 +79,10 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     }
 
     // pair 0: X = q_l (layer index j+1), Y = A_{l-1} (index j);  pair 1: X = zbar_l, Y = s_{l-1}
-    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer;
-    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer;
-    const float* Y0 = a.A + (int64_t)j * a.stash_layer;
-    const float* Y1 = a.S + (int64_t)j * a.stash_layer;
+    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer + xrow;
+    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer + xrow;
+    const float* Y0 = a.A + (int64_t)j * a.stash_layer + yrow;
+    const float* Y1 = a.S + (int64_t)j * a.stash_layer + yrow;
 
     f32x4 rx[NLD], ry[NLD];
     auto issue = [&](int pair, int step) {
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
         if (it + 1 < nit) issue(pair_of(it + 1), step_of(it + 1));      // next stage: global -> registers
         // bias mask of this stage's columns: k index 2*kk+hh is a value column always (plain range) or when
         // (2*kk+hh) % 4 == 0 (Hessian range: stages never straddle the two ranges)
-        const float bflag = (pair_of(it) == 1 && wi == 0) ? 1.f : 0.f;
+        const float bflag = (pair_of(it) == 1 && wi == 0 && i_off == 0) ? 1.f : 0.f;
         const bool hstage = (int64_t)step_of(it) * KT < a.ncol_h;
         const float f_even = hstage ? (hh == 0 ? bflag : 0.f) : bflag;
         const float f_odd = hstage ? 0.f : bflag;
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     }
 
     // D layout 32x32: col = lane&31 (input index i), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output index o)
-    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride;
-    float* dB = dW + (int64_t)H * H;
+    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)o_off * a.Hs + i_off;
+    float* dB = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)a.Hs * a.Hs + o_off;
     if (nit > 0) {
 #pragma unroll
         for (int m = 0; m < W::MT; ++m) {
@@ -166,12 +171,12 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) {
                     const int i = (wi * W::NTL + n) * 32 + l32;
-                    atomicAdd(dW + (int64_t)o * H + i, acc[m][n][e]);
+                    atomicAdd(dW + (int64_t)o * a.Hs + i, acc[m][n][e]);
                 }
             }
             // lane (l32, hh) summed zbar[feature l32] over the points of parity hh
             const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
-            if (wi == 0 && hh == 0) atomicAdd(dB + (wo * W::MT + m) * 32 + l32, tot);
+            if (wi == 0 && hh == 0 && i_off == 0) atomicAdd(dB + (wo * W::MT + m) * 32 + l32, tot);
         }
     }
 }
@@ -254,6 +259,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
     const int steps16 = a.steps_total * (KT / KB);
     const int s0 = (int)((int64_t)steps16 * blockIdx.y / nsplit);
     const int s1 = (int)((int64_t)steps16 * (blockIdx.y + 1) / nsplit);
+    const int tz = a.Hs / H;
+    const int o_off = (blockIdx.z / tz) * H, i_off = (blockIdx.z % tz) * H;
+    const int64_t xrow = (int64_t)(o_off / 4) * a.np * 4, yrow = (int64_t)(i_off / 4) * a.np * 4;
 
     f32x16 acc[W::MT][W::NTL];
     float bsum[W::MT];
@@ -265,10 +273,10 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
         bsum[m] = 0.f;
     }
-    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer;
-    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer;
-    const float* Y0 = a.A + (int64_t)j * a.stash_layer;
-    const float* Y1 = a.S + (int64_t)j * a.stash_layer;
+    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer + xrow;
+    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer + xrow;
+    const float* Y0 = a.A + (int64_t)j * a.stash_layer + yrow;
+    const float* Y1 = a.S + (int64_t)j * a.stash_layer + yrow;
 
     const int npair = a.have_g ? 2 : 1;
     const int nit = npair * (s1 - s0);
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
         // the ring slot of stage it+3 was read in iteration it-1; every wave is past that iteration's barrier
         if (it + NRING - 1 < nit) issue(it + NRING - 1);
         const float* buf = lds + (it % NRING) * STAGE;
-        const float bflag = (pair_of(it) == 1 && wi == 0) ? 1.f : 0.f;
+        const float bflag = (pair_of(it) == 1 && wi == 0 && i_off == 0) ? 1.f : 0.f;
         const bool hstage = (int64_t)step_of(it) * KB < a.ncol_h;
         const float f_other = hstage ? 0.f : 1.f;
         const int c0 = 8 * hh;                                    // MFMA k = 8*(lane>>5) + jj -> column c0 + jj
@@ -349,8 +357,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
         __syncthreads();
     }
 
-    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride;
-    float* dB = dW + (int64_t)H * H;
+    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)o_off * a.Hs + i_off;
+    float* dB = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)a.Hs * a.Hs + o_off;
     if (nit > 0) {
 #pragma unroll
         for (int m = 0; m < W::MT; ++m) {
@@ -360,11 +368,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) {
                     const int i = (wi * W::NTL + n) * 32 + l32;
-                    atomicAdd(dW + (int64_t)o * H + i, acc[m][n][e]);
+                    atomicAdd(dW + (int64_t)o * a.Hs + i, acc[m][n][e]);
                 }
             }
             const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
-            if (wi == 0 && hh == 0) atomicAdd(dB + (wo * W::MT + m) * 32 + l32, tot);
+            if (wi == 0 && hh == 0 && i_off == 0) atomicAdd(dB + (wo * W::MT + m) * 32 + l32, tot);
         }
     }
 }
@@ -452,7 +460,8 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     const size_t smem_bf = (size_t)NRING * 2 * (H / 4) * KB * 4 * sizeof(float);   // ring of 4 x (X image + Y image)
     const int nl = a.L - 1;
     if (nl <= 0) return 0;
-    int nsplit = 256 / nl;                               // one resident workgroup per CU, a single round
+    const int tz = a.Hs / H, ntz = tz * tz;              // output tiles of a layer wider than the 256 x 256 tile
+    int nsplit = 256 / (nl * ntz);                       // one resident workgroup per CU, a single round
     if (nsplit > a.steps_total) nsplit = a.steps_total;
     if (nsplit < 1) nsplit = 1;
     static bool attr_done = false;
@@ -465,7 +474,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     // DUDF_WGRAD=f32 selects the f32-input MFMA kernel (A/B testing); default: bf16x6 at fp32 accuracy
     static const bool use_f32 = [] { const char* e = getenv("DUDF_WGRAD"); return e && e[0] == 'f'; }();
     if (use_f32) {
-        hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit), dim3(NTHR), smem, st, a);
+        hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem, st, a);
     } else {
         static bool attr2 = false;
         if (!attr2) {
@@ -474,7 +483,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
             attr2 = true;
         }
-        hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit), dim3(NTHR), smem_bf, st, a);
+        hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_bf, st, a);
     }
     return (int)hipGetLastError();
 }
@@ -486,7 +495,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S; a.ncol_h = lo.ncol_h;
     a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.np / KT); a.L = lo.L;
-    a.have_g = have_g;
+    a.have_g = have_g; a.Hs = lo.H;
     int rc = 0;
     {
         DudfProfScope prof(PROF_WGRAD_HIDDEN, st);
@@ -495,6 +504,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
             case 64: rc = launch_hidden<64>(a, st); break;
             case 128: rc = launch_hidden<128>(a, st); break;
             case 256: rc = launch_hidden<256>(a, st); break;
+            case 512: rc = launch_hidden<256>(a, st); break;      // 2 x 2 output tiles of 256 x 256
             default: return DUDF_E_BADCFG;
         }
     }

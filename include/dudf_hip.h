@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DUDF_E_BADCFG   (-1)   /* unsupported network shape (hidden widths must be equal, in {32,64,128,256}) */
+#define DUDF_E_BADCFG   (-1)   /* unsupported network shape (hidden widths must be equal, in {32,64,128,256,512}; 512: no Hessian path) */
 #define DUDF_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define DUDF_E_BADMODE  (-3)
 #define DUDF_E_UNSUPPORTED (-4)

@@ -52,9 +52,10 @@ def dev(a):
 
 
 NETS = [([32, 32, 32], 63, 7), ([64] * 4, 200, 11), ([128] * 3, 130, 5), ([256] * 8, 1000, 123)]
+NETS_WIDE = NETS + [([512] * 3, 300, 9)]          # BASELINE configs[2]'s width (8x512 is exercised by bench.py --hidden 512)
 
 
-@pytest.mark.parametrize("hidden,n,seed", NETS)
+@pytest.mark.parametrize("hidden,n,seed", NETS_WIDE)
 def test_query_value_and_gradient(hip, hidden, n, seed):
     P, theta, x, _, _ = setup(hidden, n, seed)
     cfg = hip.make_cfg(hidden)
@@ -67,7 +68,7 @@ def test_query_value_and_gradient(hip, hidden, n, seed):
     assert g2 is None and rel(f2.cpu().numpy(), y_ref) < TOL_F
 
 
-@pytest.mark.parametrize("hidden,n,seed", NETS)
+@pytest.mark.parametrize("hidden,n,seed", NETS_WIDE)
 @pytest.mark.parametrize("case,mode,w", [("s1eik", "s1", W_S1EIK), ("siren", "siren", W_SIREN)])
 def test_loss_and_parameter_gradient(hip, hidden, n, seed, case, mode, w):
     P, theta, x, nrm, sdf = setup(hidden, n, seed)
@@ -105,7 +106,7 @@ def test_loss_and_parameter_gradient(hip, hidden, n, seed, case, mode, w):
     assert rel(dth2.cpu().numpy(), flat(g2)) < TOL_DTHETA
 
 
-@pytest.mark.parametrize("hidden,n,seed", NETS)
+@pytest.mark.parametrize("hidden,n,seed", NETS_WIDE)
 def test_loss_s2(hip, hidden, n, seed):
     P, theta, x, nrm, sdf = setup(hidden, n, seed)
     cfg = hip.make_cfg(hidden)
@@ -204,3 +205,6 @@ def test_unsupported_configs_fail_loudly(hip):
         hip.make_cfg([64, 32])
     with pytest.raises(_lib.DudfError):
         hip.query(hip.make_cfg([48, 48]), th, z)
+    cfg5 = hip.make_cfg([512] * 2)                  # Hessian path is not built for H = 512
+    with pytest.raises(_lib.DudfError):
+        hip.query_hessian(cfg5, torch.zeros(hip.theta_count(cfg5), device="cuda"), z)
