@@ -41,6 +41,8 @@ SYMBOLS = {
     "dudf_workspace_bytes_hess": (ctypes.c_size_t, [_CFG, ctypes.c_int64, ctypes.c_int64]),
     "dudf_workspace_bytes_query": (ctypes.c_size_t, [_CFG, ctypes.c_int64, ctypes.c_int64]),
     "dudf_query_frame": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_workspace_bytes_curvature": (ctypes.c_size_t, [_CFG, ctypes.c_int64]),
+    "dudf_query_curvature": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_grid_fields": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_double, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_query": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),

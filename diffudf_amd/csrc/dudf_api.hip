@@ -178,6 +178,64 @@ int dudf_query_frame(const dudf_net_cfg* cfg, const float* theta, const float* x
     return dudf_launch_field_features(c.lo, c.ws, 0, 1.0, nullptr, nullptr, nullptr, out_lambda, out_v, c.st);
 }
 
+}  // extern "C"
+
+namespace {
+// curvature query workspace = [Hessian-query layout of n points][lam 3n][V 9n][jet x4 4*npj][jet y npj]
+struct CurvLayout { DudfLayout q; int64_t npj, o_lam, o_V, o_x4, o_y; size_t total_bytes; };
+int make_curv_layout(const dudf_net_cfg* cfg, int64_t n, CurvLayout* cl) {
+    int rc = dudf_make_layout(cfg, n, n, &cl->q, 1);
+    if (rc) return rc;
+    if (cl->q.H > 256) return DUDF_E_UNSUPPORTED;
+    cl->npj = (16 * n + DUDF_TILE_PTS - 1) / DUDF_TILE_PTS * DUDF_TILE_PTS;
+    if (cl->npj == 0) cl->npj = DUDF_TILE_PTS;
+    if (cl->npj > (1ll << 26)) return DUDF_E_BADCFG;
+    int64_t o = (int64_t)(cl->q.total_bytes / sizeof(float));
+    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) / 4 * 4; return r; };
+    cl->o_lam = take(3 * n); cl->o_V = take(9 * n); cl->o_x4 = take(4 * cl->npj); cl->o_y = take(cl->npj);
+    cl->total_bytes = (size_t)o * sizeof(float);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t dudf_workspace_bytes_curvature(const dudf_net_cfg* cfg, int64_t n) {
+    CurvLayout cl;
+    if (make_curv_layout(cfg, n, &cl)) return 0;
+    return cl.total_bytes;
+}
+
+int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+                         float* out_lambda, float* out_v, float* out_mean, float* out_gauss, float* out_shape,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    CurvLayout cl;
+    int rc = make_curv_layout(cfg, n, &cl);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < cl.total_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return DUDF_E_WORKSPACE;
+    if (n <= 0) return 0;
+    Ctx c;
+    c.lo = cl.q; c.st = reinterpret_cast<hipStream_t>(stream); c.ws = reinterpret_cast<float*>(workspace);
+    if ((rc = check_ws(c.lo, workspace, workspace_bytes))) return rc;
+    // 1. value, df/dx, Hessian (forward-over-reverse quads) and the eigen-frame of the Hessian
+    if ((rc = forward_common(c, theta, x, 0, true))) return rc;
+    float* lam = c.ws + cl.o_lam; float* V = c.ws + cl.o_V;
+    if ((rc = dudf_launch_field_features(c.lo, c.ws, 0, 1.0, nullptr, nullptr, nullptr, lam, V, c.st))) return rc;
+    // 2. third-order Taylor jet in the three frame directions: one 16-column tile per point
+    if ((rc = dudf_launch_make_x4_jet(x, V, n, cl.npj, c.ws + cl.o_x4, c.st))) return rc;
+    SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
+    a.x4 = c.ws + cl.o_x4; a.y = c.ws + cl.o_y; a.np = cl.npj; a.stash_layer = (int64_t)c.lo.H * cl.npj;
+    a.tile0 = 0; a.ntiles = (int)(cl.npj / DUDF_TILE_PTS); a.hess = 1;
+    if ((rc = dudf_launch_sweep(SWEEP_FWD_J, c.lo.H, a, c.st))) return rc;
+    // 3. first-order eigenvector perturbation
+    if ((rc = dudf_launch_curvature(c.ws + cl.o_y, lam, V, n, out_mean, out_gauss, out_shape, c.st))) return rc;
+    hipError_t e = hipSuccess;
+    if (out_lambda) e = hipMemcpyAsync(out_lambda, lam, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+    if (e == hipSuccess && out_v) e = hipMemcpyAsync(out_v, V, (size_t)n * 9 * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+    return (int)e;
+}
+
 int dudf_grid_fields(const dudf_net_cfg* cfg, const float* theta, int64_t grid_n, int64_t start, int64_t count,
                      int inverse_mode, double alpha, float* out_df, float* out_vec, int* out_flag_count,
                      void* workspace, size_t workspace_bytes, void* stream) {

@@ -110,7 +110,8 @@ struct SweepArgs {
 };
 
 enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,
-       SWEEP_FWD_H = 4, SWEEP_REV_H = 5, SWEEP_ADJ_FWD_H = 6, SWEEP_ADJ_REV_H = 7 };   // Hessian-quad variants
+       SWEEP_FWD_H = 4, SWEEP_REV_H = 5, SWEEP_ADJ_FWD_H = 6, SWEEP_ADJ_REV_H = 7,     // Hessian-quad variants
+       SWEEP_FWD_J = 8 };                                                              // third-order jets (query)
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
 
@@ -133,6 +134,11 @@ int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, in
 int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st);
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, float* out_h,
                          hipStream_t st);
+// third-order jets: x4 of n points x one 16-column tile (value + the eigen-frame V as three directions), and the
+// epilogue that turns the jets' mixed third-order coefficients into curvature
+int dudf_launch_make_x4_jet(const float* x, const float* V, int64_t n, int64_t npj, float* x4j, hipStream_t st);
+int dudf_launch_curvature(const float* yj, const float* lam, const float* V, int64_t n, float* out_mean,
+                          float* out_gauss, float* out_shape, hipStream_t st);
 
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,

@@ -449,6 +449,69 @@ __global__ __launch_bounds__(256) void field_features_kernel(const float* __rest
     }
 }
 
+// ---- third-order jets for the curvature query (reference src/render_st.py:42-55) ------------------------------------
+// One 16-column tile per point: column 0 = (x, 1), columns 1..3 = the eigen-frame A = v_0, B = v_1, C = v_2 = n of the
+// Hessian as directions, the rest zero; SWEEP_FWD_J (dudf_sweep.hip) turns them into the Taylor coefficients y_m of
+// f(x + sA + rB + tC) for the monomials listed there.  Mixed third derivatives in the frame:
+//   T(A,A,C) = 2 y_sst, T(B,B,C) = 2 y_rrt, T(A,B,C) = y_srt, T(A,C,C) = 2 y_stt, T(B,C,C) = 2 y_rtt
+// and the shape operator  J_ik = dn_i/dx_k = sum_{j<2} (v_j)_i T(v_j, n, e_k) / (lam_2 - lam_j)  (first-order perturbation
+// of the top eigenvector of the Hessian — what autograd through torch.linalg.eigh returns), e_k expanded in the frame.
+// mean = tr J / 2 = [T(A,A,C)/(lam_2-lam_0) + T(B,B,C)/(lam_2-lam_1)]/2.
+__global__ __launch_bounds__(256) void make_x4_jet_kernel(const float* __restrict__ x, const float* __restrict__ V,
+                                                          int64_t n, int64_t npj, float* __restrict__ x4j) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < npj; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = c >> 4;
+        const int li = (int)(c & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p < n) {
+            if (li == 0) v = f32x4{x[p * 3], x[p * 3 + 1], x[p * 3 + 2], 1.f};
+            else if (li <= 3) v = f32x4{V[p * 9 + li - 1], V[p * 9 + 3 + li - 1], V[p * 9 + 6 + li - 1], 0.f};
+        }
+        *reinterpret_cast<f32x4*>(x4j + c * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void curvature_kernel(const float* __restrict__ yj, const float* __restrict__ lam,
+                                                        const float* __restrict__ V, int64_t n,
+                                                        float* __restrict__ out_mean, float* __restrict__ out_gauss,
+                                                        float* __restrict__ out_shape) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const float* yp = yj + p * 16;
+        const double g0 = (double)lam[p * 3 + 2] - (double)lam[p * 3], g1 = (double)lam[p * 3 + 2] - (double)lam[p * 3 + 1];
+        const double Taac = 2.0 * yp[10], Tbbc = 2.0 * yp[11], Tabc = yp[12], Tacc = 2.0 * yp[13], Tbcc = 2.0 * yp[14];
+        if (out_mean) out_mean[p] = (float)(0.5 * (Taac / g0 + Tbbc / g1));
+        if (out_shape || out_gauss) {
+            double J[3][3], A[3], B[3], C[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { A[i] = V[p * 9 + i * 3]; B[i] = V[p * 9 + i * 3 + 1]; C[i] = V[p * 9 + i * 3 + 2]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double w0k = (A[k] * Taac + B[k] * Tabc + C[k] * Tacc) / g0;
+                const double w1k = (A[k] * Tabc + B[k] * Tbbc + C[k] * Tbcc) / g1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) J[i][k] = A[i] * w0k + B[i] * w1k;
+            }
+            if (out_shape)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) out_shape[p * 9 + i * 3 + k] = (float)J[i][k];
+            if (out_gauss) {
+                // -det [[J, n], [n^T, 0]]  (reference src/render_st.py:48-53) = sum_ik n_i n_k cof(J)_ik
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                        acc += C[i] * C[k] * (J[i1][k1] * J[i2][k2] - J[i1][k2] * J[i2][k1]);
+                    }
+                out_gauss[p] = (float)acc;
+            }
+        }
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -555,6 +618,20 @@ int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStre
     DudfProfScope prof(PROF_OTHER, st);
     hipLaunchKernelGGL(make_x4_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, x, ws + lo.ws_x4, lo.n, lo.n_h,
                        lo.ncol_h, lo.np);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_make_x4_jet(const float* x, const float* V, int64_t n, int64_t npj, float* x4j, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(make_x4_jet_kernel, dim3(grid_for(npj)), dim3(256), 0, st, x, V, n, npj, x4j);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_curvature(const float* yj, const float* lam, const float* V, int64_t n, float* out_mean,
+                          float* out_gauss, float* out_shape, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(curvature_kernel, dim3(grid_for(n)), dim3(256), 0, st, yj, lam, V, n, out_mean, out_gauss,
+                       out_shape);
     return (int)hipGetLastError();
 }
 

@@ -10,6 +10,10 @@
 // The reference stores the SIGNED distance open3d returns; every consumer (loss_s1 / loss_s2,
 // src/loss_functions.py:131-136) is even in it, so the unsigned distance is written.
 //
+// Point-cloud-only input (n_tri == 0; reference src/dataset.py:80-131 `sampleTrainingDataPC`): the far distance is the
+// distance to the nearest CLOUD POINT (reference :72-78 `shortestDistance`, evaluated here as min |p - x| instead
+// of its expanded |x|^2 - 2 p.x + |p|^2 form) and the near distance is |offset| (reference :108-110), no query.
+//
 // Random numbers are counter-based — a pure function of (seed, step, stream, GLOBAL sample index), the same
 // splitmix64 construction as diffudf_amd/synth.py — so rank r of W produces exactly its slice of the global batch
 // and the numpy restatement in oracle/sampler_oracle.py reproduces every sample.
@@ -98,8 +102,9 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
     const int64_t n_l = n_on_l + n_far_l + n_near_l;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n_l;
-    float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, known = 0.f;
     bool query = false;
+    const bool cloud_only = a.n_tri == 0;
     if (live) {
         if (i < n_on_l) {
             const int64_t g = a.on0 + i;
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
             px = __fadd_rn(a.pc_pos[c * 3], __fmul_rn(a.pc_nrm[c * 3], off));
             py = __fadd_rn(a.pc_pos[c * 3 + 1], __fmul_rn(a.pc_nrm[c * 3 + 1], off));
             pz = __fadd_rn(a.pc_pos[c * 3 + 2], __fmul_rn(a.pc_nrm[c * 3 + 2], off));
-            query = true;
+            query = !cloud_only;
+            known = fabsf(off);
         }
     }
     float best = 3.0e38f;
@@ -133,10 +139,22 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
         if (query)
             for (int t = 0; t < cnt; ++t) best = fminf(best, tri_dist2(px, py, pz, tl + t * 9));
     }
+    if (cloud_only)
+        for (int64_t t0 = 0; t0 < a.n_pc; t0 += TRI_TILE * 3) {         // the same LDS tile holds 768 cloud points
+            const int cnt = (int)((a.n_pc - t0 < TRI_TILE * 3) ? a.n_pc - t0 : TRI_TILE * 3);
+            __syncthreads();
+            for (int e = threadIdx.x; e < cnt * 3; e += blockDim.x) tl[e] = a.pc_pos[t0 * 3 + e];
+            __syncthreads();
+            if (query)
+                for (int t = 0; t < cnt; ++t) {
+                    const float dx = px - tl[t * 3], dy = py - tl[t * 3 + 1], dz = pz - tl[t * 3 + 2];
+                    best = fminf(best, dx * dx + dy * dy + dz * dz);
+                }
+        }
     if (live) {
         a.x[i * 3] = px; a.x[i * 3 + 1] = py; a.x[i * 3 + 2] = pz;
         a.normals[i * 3] = nx; a.normals[i * 3 + 1] = ny; a.normals[i * 3 + 2] = nz;
-        a.sdf[i] = query ? sqrtf(best) : 0.f;
+        a.sdf[i] = query ? sqrtf(best) : known;
     }
 }
 
@@ -146,7 +164,7 @@ extern "C" int dudf_sample_batch(const float* tri, int64_t n_tri, const float* p
                                  int64_t n_pc, int64_t n_on, int64_t n_far, int64_t n_near, uint64_t seed,
                                  uint64_t step, int rank, int world, float* x, float* normals, float* sdf,
                                  void* stream) {
-    if (n_tri <= 0 || n_pc <= 0 || world < 1 || rank < 0 || rank >= world || n_on < 0 || n_far < 0 || n_near < 0)
+    if (n_tri < 0 || (n_tri > 0 && !tri) || n_pc <= 0 || world < 1 || rank < 0 || rank >= world || n_on < 0 || n_far < 0 || n_near < 0)
         return DUDF_E_BADCFG;
     if (n_near > 0 && n_on == 0) return DUDF_E_BADCFG;
     SampleArgs a;

@@ -116,7 +116,8 @@ __device__ __forceinline__ float quad_sum(float v) {             // sum over the
     return v;
 }
 
-constexpr bool is_hess(int SW) { return SW >= 4; }
+constexpr bool is_hess(int SW) { return SW >= 4; }      // channels that are not all "value" columns (quads, jets)
+constexpr bool is_jet(int SW) { return SW == SWEEP_FWD_J; }
 constexpr int base_of(int SW) { return SW & 3; }
 
 // Elementwise tail of one 16-feature x 16-column tile.
@@ -131,6 +132,40 @@ constexpr int base_of(int SW) { return SW & 3; }
 //              E = w0 c sbar_rev - w0 s cbar_rev | zdotbar_rev^k = -w0 s chat^k, chat^k = w0 a Qdot^k,
 //              cbar_rev = w0 a Q + w0 sum_k adot^k Qdot^k, sbar_rev = -w0 sum_k zdot^k chat^k
 //   ADJ_REV_H  hbar|hdotbar^k  -> zbar = E + w0 c hbar - w0^2 s sum_k zdot^k hdotbar^k | zdotbar^k = E + w0 c hdotbar^k
+// Third-order jets (SWEEP_FWD_J, query only, nothing stashed): a 16-column tile is ONE point — its columns carry the
+// Taylor coefficients of  (s,r,t) -> z(x + s A + r B + t C)  for the monomials
+//   0: 1 | 1: s  2: r  3: t | 4: ss  5: rr  6: tt  7: sr  8: st  9: rt | 10: sst  11: rrt  12: srt  13: stt  14: rtt | 15: 0
+// (A, B, C = the three direction columns of x4).  The matmuls act on every coefficient alike; the sine composes them:
+// with u = w0 (z - z_0), sin(w0 z) = s + c u - s u^2/2 - c u^3/6 + ..., i.e. for monomial m
+//   h_m = c U_m - s [m](u^2/2) - c [m](u^3/6),     U_m = w0 z_m
+// e.g. [ss] = U_s^2/2, [st] = U_s U_t, [sst](u^2/2) = U_ss U_t + U_s U_st, [sst](u^3/6) = U_s^2 U_t/2,
+// [srt](u^2/2) = U_sr U_t + U_st U_r + U_rt U_s, [srt](u^3/6) = U_s U_r U_t.  kJetLane packs, per monomial, which
+// lanes of the 16-group feed those products.  2 y_sst = d^3 f[A,A,C] etc. are the mixed third derivatives the
+// curvature of the Hessian's eigenvector field needs (reference src/render_st.py:42-55), without the cancellation a
+// polarisation of pure directional derivatives would suffer.
+// word: bits 0-3/4-7/8-11 second-order source lanes (15 = the zero column), 12-13/14-15/16-17 the first-order factor
+// paired with each, 18-19/20-21/22-23 factors a,b,c of the pure first-order product, 24-25 weight of F_a F_b in u^2/2
+// (0, 1 = 1/2, 2 = 1), 26-27 weight of F_a F_b F_c in u^3/6, bit 28: value column.
+constexpr unsigned jet_word(int sl0, int f0, int sl1, int f1, int sl2, int f2, int a, int b, int c, int w2, int w3,
+                            int isval = 0) {
+    return (unsigned)sl0 | ((unsigned)sl1 << 4) | ((unsigned)sl2 << 8) | ((unsigned)f0 << 12) | ((unsigned)f1 << 14) |
+           ((unsigned)f2 << 16) | ((unsigned)a << 18) | ((unsigned)b << 20) | ((unsigned)c << 22) |
+           ((unsigned)w2 << 24) | ((unsigned)w3 << 26) | ((unsigned)isval << 28);
+}
+__constant__ unsigned kJetLane[16] = {
+    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0, 1),                                   // value
+    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0), jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0),
+    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0),                                      // s, r, t
+    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 1, 0), jet_word(15, 0, 15, 0, 15, 0, 1, 1, 0, 1, 0),   // ss, rr
+    jet_word(15, 0, 15, 0, 15, 0, 2, 2, 0, 1, 0), jet_word(15, 0, 15, 0, 15, 0, 0, 1, 0, 2, 0),   // tt, sr
+    jet_word(15, 0, 15, 0, 15, 0, 0, 2, 0, 2, 0), jet_word(15, 0, 15, 0, 15, 0, 1, 2, 0, 2, 0),   // st, rt
+    jet_word(4, 2, 8, 0, 15, 0, 0, 0, 2, 0, 1),                                        // sst: ss*t + st*s ; s s t / 2
+    jet_word(5, 2, 9, 1, 15, 0, 1, 1, 2, 0, 1),                                        // rrt: rr*t + rt*r ; r r t / 2
+    jet_word(7, 2, 8, 1, 9, 0, 0, 1, 2, 0, 2),                                         // srt: sr*t + st*r + rt*s ; s r t
+    jet_word(6, 0, 8, 2, 15, 0, 2, 2, 0, 0, 1),                                        // stt: tt*s + st*t ; t t s / 2
+    jet_word(6, 1, 9, 2, 15, 0, 2, 2, 1, 0, 1),                                        // rtt: tt*r + rt*t ; t t r / 2
+    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0)};                                     // spare: stays zero
+
 template <int SW, int FL>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
                                           unsigned vo, bool isv) {
@@ -199,6 +234,24 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         *DUDF_AT(a.A, ub, vo) = out;
         *DUDF_AT(a.E, ub, vo) = e;
+    } else if constexpr (SW == SWEEP_FWD_J) {
+        const int lane = threadIdx.x & 63, l0 = lane & 48;
+        const unsigned jw = kJetLane[lane & 15];
+        const float w2 = 0.5f * (float)((jw >> 24) & 3), w3 = 0.5f * (float)((jw >> 26) & 3);
+        const bool isval = (jw >> 28) & 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float sv, cv;
+            dudf_sincos(a.w0 * __shfl(acc[t], l0), &sv, &cv);
+            const float F[3] = {a.w0 * __shfl(acc[t], l0 + 1), a.w0 * __shfl(acc[t], l0 + 2), a.w0 * __shfl(acc[t], l0 + 3)};
+            auto sel = [&](unsigned k) -> float { k &= 3; return k == 0 ? F[0] : (k == 1 ? F[1] : F[2]); };
+            const float S0 = a.w0 * __shfl(acc[t], l0 + (int)(jw & 15)), S1 = a.w0 * __shfl(acc[t], l0 + (int)((jw >> 4) & 15)),
+                        S2 = a.w0 * __shfl(acc[t], l0 + (int)((jw >> 8) & 15));
+            const float fab = sel(jw >> 18) * sel(jw >> 20);
+            const float p2 = S0 * sel(jw >> 12) + S1 * sel(jw >> 14) + S2 * sel(jw >> 16) + w2 * fab;
+            const float p3 = w3 * fab * sel(jw >> 22);
+            out[t] = isval ? sv : cv * (a.w0 * acc[t] - p3) - sv * p2;
+        }
     } else {                                         // SWEEP_ADJ_REV_H: o1 = c, o2 = s|zdot^k, o3 = E
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -252,6 +305,7 @@ constexpr int younger_ops() {
          : SW == SWEEP_FWD_H ? 2 + 2 * (2 + (FL & 1))                   // bias + C,ZS(,S) stores
          : SW == SWEEP_REV_H ? 4 + ((FL & 1) ? 4 : 0)                   // c,zs loads + Q,R stores
          : SW == SWEEP_ADJ_FWD_H ? 6 + 4                                // c,zs,aa loads + A,E stores
+         : SW == SWEEP_FWD_J ? 2                                        // bias loads only
          : 6 + 2;                                                       // c,zs,E loads + Z stores
 }
 template <int H, int N>
@@ -278,7 +332,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
     constexpr bool HS = is_hess(SW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const bool isv = !HS || (lane & 3) == 0;           // value channel (always, on the plain path)
+    const bool isv = !HS || (is_jet(SW) ? li == 0 : (lane & 3) == 0);   // value channel (always, on the plain path)
     const int nhid = a.L - 1;                          // hidden x hidden layers
     constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
 
@@ -439,7 +493,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
             }
             part += __shfl_xor(part, 16);               // the 4 lane quarters hold disjoint feature rows
             part += __shfl_xor(part, 32);
-            part += a.theta[a.off_bo];
+            if (isv) part += a.theta[a.off_bo];         // tangent / jet columns are derivatives: no constant term
             if (q == 0) a.y[p] = part;
             res[0] = part;
         } else if constexpr (BS == SWEEP_REV) {         // a_0 = W_1^T q_1 (rows 0..2 of a 16-row tile): df/dx | Hessian column
@@ -512,6 +566,9 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
             break;
         case SWEEP_ADJ_REV_H:
             if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_ADJ_REV_H, 0);
+            break;
+        case SWEEP_FWD_J:
+            if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_FWD_J, 0);
             break;
         default: return DUDF_E_BADMODE;
     }

@@ -61,19 +61,19 @@ class PointCloud:
     when those do not exist `<prefix>.obj` is normalised and sampled in memory (diffudf_amd/mesh.py).  Every batch is
     produced on the GPU by `dudf_sample_batch` and yielded as DEVICE tensors (the loop's `.to(device)` is then a
     no-op), ordered [on | far | near] exactly like the reference.  `rank`/`world` shard each stratum.
-    `onlyPCloud=True` (point-cloud input, reference :80-131) is not built."""
+    `onlyPCloud=True` (point-cloud input, reference :80-131): only `<prefix>_pc.ply` (or the in-memory cloud) is used;
+    far distances go to the nearest cloud point and near distances are |offset|."""
 
     def __init__(self, meshPath, batchSize, samplingPercentiles, batchesPerEpoch, device=None, onlyPCloud=False,
                  seed=123, rank=0, world=1, surfacePoints=100000):
         import ctypes
         from . import _lib, mesh
-        if onlyPCloud:
-            raise NotImplementedError("PointCloud(onlyPCloud=True): the point-cloud-only sampler is not built")
+        self.onlyPCloud = bool(onlyPCloud)
         self.device = torch.device("cuda", 0) if device is None else torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DudfError("PointCloud: the sampler runs on the GPU; there is no CPU fallback path")
-        tri, pos, nrm = mesh.prepare(meshPath, surfacePoints, seed)
-        self.tri = torch.from_numpy(tri).to(self.device)
+        tri, pos, nrm = mesh.prepare(meshPath, surfacePoints, seed, cloud_only=self.onlyPCloud)
+        self.tri = None if self.onlyPCloud else torch.from_numpy(tri).to(self.device)
         self.pc_pos = torch.from_numpy(pos).to(self.device)
         self.pc_nrm = torch.from_numpy(nrm).to(self.device)
         self.batchSize, self.batchesPerEpoch = batchSize, batchesPerEpoch
@@ -100,7 +100,8 @@ class PointCloud:
         sdf = torch.empty(n, dtype=torch.float32, device=self.device)
         P = lambda t: ct.c_void_p(t.data_ptr())   # noqa: E731
         with torch.cuda.device(self.device):
-            rc = lib.dudf_sample_batch(P(self.tri), self.tri.shape[0], P(self.pc_pos), P(self.pc_nrm),
+            rc = lib.dudf_sample_batch(P(self.tri) if self.tri is not None else None,
+                                       self.tri.shape[0] if self.tri is not None else 0, P(self.pc_pos), P(self.pc_nrm),
                                        self.pc_pos.shape[0], self.samplesOnSurface, self.n_far, self.n_near,
                                        self.seed, step, self.rank, self.world, P(x), P(nrm), P(sdf),
                                        ct.c_void_p(torch.cuda.current_stream().cuda_stream))

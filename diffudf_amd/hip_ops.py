@@ -138,6 +138,33 @@ def query_frame(cfg, theta, x, ws=None):
     return f, g, h, lam, v
 
 
+def query_curvature(cfg, theta, x, want_shape=False, chunk=65536):
+    """Eigen-frame of the Hessian and the curvature of its top-eigenvector field (reference src/render_st.py:42-62):
+    lam (n,3), V (n,3,3) [normal = V[:,:,2]], mean (n,), and with want_shape also gaussian (n,) and the shape operator
+    J (n,3,3) = d normal_i / d x_k; (None, None) otherwise.  Runs in chunks so the scratch stays a few GB."""
+    lib = _lib.load()
+    x = _f32(x, "x").view(-1, 3)
+    theta = _f32(theta, "theta")
+    n, dev = x.shape[0], x.device
+    lam = torch.empty(n, 3, dtype=torch.float32, device=dev); v = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
+    mean = torch.empty(n, dtype=torch.float32, device=dev)
+    gauss = torch.empty(n, dtype=torch.float32, device=dev) if want_shape else None
+    shape = torch.empty(n, 3, 3, dtype=torch.float32, device=dev) if want_shape else None
+    m = min(max(n, 1), int(chunk))
+    nbytes = int(lib.dudf_workspace_bytes_curvature(ctypes.byref(cfg), m))
+    if nbytes == 0:
+        _lib.check(-4 if cfg.hidden > 256 else -1, "dudf_workspace_bytes_curvature")
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    for s in range(0, n, m):
+        e = min(s + m, n)
+        rc = lib.dudf_query_curvature(ctypes.byref(cfg), _ptr(theta), _ptr(x[s:e]), e - s,
+                                      _ptr(lam[s:e]), _ptr(v[s:e]), _ptr(mean[s:e]),
+                                      _ptr(gauss[s:e]) if want_shape else None,
+                                      _ptr(shape[s:e]) if want_shape else None, _ptr(buf), nbytes, _stream())
+        _lib.check(rc, "dudf_query_curvature")
+    return lam, v, mean, gauss, shape
+
+
 INVERSE_MODES = {"tanh": 0, "siren": 1, "squared": 2}
 
 

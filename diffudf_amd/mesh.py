@@ -129,12 +129,16 @@ def write_obj(path, verts, tris):
             f.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
 
 
-def prepare(mesh_prefix, surface_points=100000, seed=123):
+def prepare(mesh_prefix, surface_points=100000, seed=123, cloud_only=False):
     """What the sampler needs for `<mesh_prefix>`: (triangle soup (T,9), cloud positions (P,3), cloud normals (P,3)).
 
     Like the reference's PointCloud (src/dataset.py:149-155) it reads `<prefix>_t.obj` and `<prefix>_pc.ply` when
     they exist (files written by the reference's preprocess.py work); otherwise it does that preprocessing
-    itself, in memory, from `<prefix>.obj`."""
+    itself, in memory, from `<prefix>.obj`.  cloud_only (reference :157-159): a `<prefix>_pc.ply` alone is enough and
+    no triangles are returned."""
+    if cloud_only and os.path.exists(mesh_prefix + "_pc.ply"):
+        pos, nrm = read_ply_points(mesh_prefix + "_pc.ply")
+        return None, pos, nrm
     t_obj, pc_ply, raw = mesh_prefix + "_t.obj", mesh_prefix + "_pc.ply", mesh_prefix + ".obj"
     if os.path.exists(t_obj):
         verts, tris = load_obj(t_obj)
@@ -147,4 +151,4 @@ def prepare(mesh_prefix, surface_points=100000, seed=123):
         pos, nrm = read_ply_points(pc_ply)
     else:
         pos, nrm = sample_surface(verts, tris, int(surface_points), seed)
-    return triangle_soup(verts, tris), pos, nrm
+    return (None if cloud_only else triangle_soup(verts, tris)), pos, nrm

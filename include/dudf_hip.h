@@ -75,6 +75,18 @@ int dudf_query_frame(const dudf_net_cfg* cfg, const float* theta, const float* x
                      float* out_f, float* out_g, float* out_h, float* out_lambda, float* out_v,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Normals and curvatures at query points — replaces `compute_normals_and_cd` + `compute_curvature` (reference
+ * src/render_st.py:57-62, :42-55): eigh of the Hessian (normal n = v_2, principal directions v_0, v_1), the shape operator
+ * J = jacobian(n, x) (src/diff_operators.py:214-227; third derivatives of f), mean = trace(J)/2,
+ * gaussian = -det [[J, n],[n^T, 0]].  The sign of n — and with it of J and of the mean curvature — is arbitrary, as it
+ * is for torch.linalg.eigh; the reference re-orients both afterwards (:104-108).
+ * out_shape (n,3,3) row-major [i][k] = dn_i/dx_k.  One 16-column third-order Taylor jet per point on top of the
+ * Hessian query (24 F0 flops per point).  Hidden width <= 256.  Any output may be NULL. */
+size_t dudf_workspace_bytes_curvature(const dudf_net_cfg* cfg, int64_t n);
+int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n,
+                         float* out_lambda, float* out_v, float* out_mean, float* out_gauss, float* out_shape,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* The field part of `extract_fields` (reference src/render_mc.py:20-99) for grid points start .. start+count-1 of the
  * regular grid_n^3 grid on [-1,1]^3 (linear index, first axis slowest, coordinates derived from the index):
  * out_df (count) = inverse(gt_mode, |f|, alpha) with inverse_mode 0 'tanh' / 1 'siren' / 2 'squared'
@@ -152,7 +164,9 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
  * src/preprocess_mesh.py:39).  Writes THIS RANK's slice of the global batch [on | far | near] of
  * n_on + n_far + n_near points: x (n_l,3), normals (n_l,3) (zero off-surface), sdf (n_l) (zero on-surface,
  * unsigned distance otherwise); slice r of W of each stratum is [m*r/W, m*(r+1)/W).  Counter-based RNG keyed by
- * (seed, step): the union over ranks does not depend on W. */
+ * (seed, step): the union over ranks does not depend on W.
+ * n_tri == 0 (tri may be NULL) selects the point-cloud-only variant, `sampleTrainingDataPC` (reference
+ * src/dataset.py:80-131): far sdf = distance to the nearest cloud point (:72-78), near sdf = |offset| (:108-110). */
 int dudf_sample_batch(const float* tri, int64_t n_tri, const float* pc_pos, const float* pc_nrm, int64_t n_pc,
                       int64_t n_on, int64_t n_far, int64_t n_near, uint64_t seed, uint64_t step, int rank, int world,
                       float* x, float* normals, float* sdf, void* stream);

@@ -407,3 +407,83 @@ def adam_step(theta, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
 # --------------------------------------------------------------------------
 def inv_tanh(pred_df, alpha):
     return np.where(pred_df < 1.0 / alpha, np.sqrt(pred_df / alpha), pred_df)
+
+
+# --------------------------------------------------------------------------
+# third derivatives and curvature of the eigenvector field  —  reference src/render_st.py:42-62
+# (`compute_normals_and_cd`: n = top eigenvector of hessian(y,x); `compute_curvature`: jacobian(n, x)
+#  [src/diff_operators.py:214-227], mean = trace/2, gaussian = -det [[J, n],[n^T, 0]])
+# --------------------------------------------------------------------------
+_MONO3 = [(i, j, k) for i in range(4) for j in range(4) for k in range(4) if i + j + k <= 3]
+
+
+def _poly_mul(a, b):
+    """Product of two trivariate polynomials truncated at total degree 3; coefficient arrays (..., 4, 4, 4)."""
+    out = np.zeros_like(a)
+    for (i, j, k) in _MONO3:
+        for (p, q, r) in _MONO3:
+            if i + p + j + q + k + r <= 3:
+                out[..., i + p, j + q, k + r] += a[..., i, j, k] * b[..., p, q, r]
+    return out
+
+
+def third_derivatives(params, x, w0=30.0):
+    """T (N,3,3,3) = d^3 f / dx_a dx_b dx_c by propagating the degree-3 Taylor polynomial of every activation in the
+    three input variables (numpy only).  Composition with sin:  sin(a+u) = s (1 - u^2/2) + c (u - u^3/6) + O(u^4)."""
+    x = np.asarray(x)
+    N = x.shape[0]
+    h = np.zeros((N, 3, 4, 4, 4), dtype=x.dtype)
+    h[:, :, 0, 0, 0] = x
+    h[:, 0, 1, 0, 0] = 1.0; h[:, 1, 0, 1, 0] = 1.0; h[:, 2, 0, 0, 1] = 1.0
+    for W, b in params[:-1]:
+        z = np.einsum("of,nfijk->noijk", W, h)
+        z[:, :, 0, 0, 0] += b
+        a0 = w0 * z[:, :, 0, 0, 0]
+        s, c = np.sin(a0)[..., None, None, None], np.cos(a0)[..., None, None, None]
+        u = w0 * z
+        u[:, :, 0, 0, 0] = 0.0
+        u2 = _poly_mul(u, u)
+        u3 = _poly_mul(u2, u)
+        h = c * (u - u3 / 6.0) - s * (u2 / 2.0)
+        h[:, :, 0, 0, 0] = s[..., 0, 0, 0]
+    Wo, bo = params[-1]
+    y = np.einsum("f,nfijk->nijk", Wo[0], h)
+    T = np.zeros((N, 3, 3, 3), dtype=x.dtype)
+    fact = [1.0, 1.0, 2.0, 6.0]
+    for a in range(3):
+        for b_ in range(3):
+            for c_ in range(3):
+                e = [0, 0, 0]
+                e[a] += 1; e[b_] += 1; e[c_] += 1
+                T[:, a, b_, c_] = y[:, e[0], e[1], e[2]] * fact[e[0]] * fact[e[1]] * fact[e[2]]
+    return T
+
+
+def shape_operator(H, T):
+    """J (N,3,3) = d n_i / d x_k for n = eigenvector of the largest eigenvalue of H (lower triangle, as eigh reads it):
+    dn/dx_k = sum_{j<2} v_j (v_j^T (dH/dx_k) n) / (lam_2 - lam_j).  Also returns (lam, V)."""
+    Hl = np.tril(H) + np.transpose(np.tril(H, -1), (0, 2, 1))
+    lam, V = np.linalg.eigh(Hl)
+    n = V[:, :, 2]
+    J = np.zeros_like(H)
+    for j in range(2):
+        vj = V[:, :, j]
+        coef = np.einsum("na,nabk,nb->nk", vj, T, n) / (lam[:, 2] - lam[:, j])[:, None]
+        J += vj[:, :, None] * coef[:, None, :]
+    return J, lam, V
+
+
+def curvatures(params, x, w0=30.0):
+    """(normal n (N,3), principal directions (N,3,2), mean (N,), gaussian (N,), J (N,3,3)) — reference
+    src/render_st.py:42-62.  The sign of n (and with it of J and of the mean curvature) is eigh's, i.e. arbitrary."""
+    y, cache = forward(params, x, w0)
+    g, rev = input_gradient(params, cache, w0)
+    H, _ = hessian(params, x, cache, rev, w0)
+    T = third_derivatives(params, x, w0)
+    J, lam, V = shape_operator(H, T)
+    n = V[:, :, 2]
+    mean = 0.5 * np.trace(J, axis1=1, axis2=2)
+    ext = np.zeros((len(x), 4, 4), dtype=J.dtype)
+    ext[:, :3, :3] = J; ext[:, :3, 3] = n; ext[:, 3, :3] = n
+    gauss = -np.linalg.det(ext)
+    return n, V[:, :, :2], mean, gauss, J

@@ -50,8 +50,19 @@ def mesh_distance(p, tri, chunk=2048):
     return out
 
 
+def cloud_distance(p, pc_pos, chunk=1024):
+    """Distance to the nearest cloud point (reference src/dataset.py:72-78 `shortestDistance`), fp64."""
+    out = np.empty(len(p))
+    X = pc_pos.astype(np.float64)
+    for i in range(0, len(p), chunk):
+        d = p[i:i + chunk, None, :].astype(np.float64) - X[None]
+        out[i:i + chunk] = np.sqrt((d * d).sum(-1).min(axis=1))
+    return out
+
+
 def sample_batch(tri, pc_pos, pc_nrm, n_on, n_far, n_near, seed, step, rank=0, world=1):
-    """This rank's slice [on | far | near]: x (n,3) f32, normals (n,3) f32, sdf (n,1) f32."""
+    """This rank's slice [on | far | near]: x (n,3) f32, normals (n,3) f32, sdf (n,1) f32.
+    tri=None: the point-cloud-only variant (reference src/dataset.py:80-131)."""
     base = 1000 * step
     P = len(pc_pos)
     sl = lambda m: (m * rank // world, m * (rank + 1) // world)   # noqa: E731
@@ -67,5 +78,8 @@ def sample_batch(tri, pc_pos, pc_nrm, n_on, n_far, n_near, seed, step, rank=0, w
     near = (pc_pos[cn] + (pc_nrm[cn] * off[:, None]).astype(np.float32)).astype(np.float32)
     x = np.concatenate([x_on, far, near]).astype(np.float32)
     nrm = np.concatenate([n_onv, np.zeros((len(far) + len(near), 3), np.float32)]).astype(np.float32)
-    sdf = np.concatenate([np.zeros(len(x_on)), mesh_distance(far, tri), mesh_distance(near, tri)]).astype(np.float32)
+    if tri is None:
+        sdf = np.concatenate([np.zeros(len(x_on)), cloud_distance(far, pc_pos), np.abs(off)]).astype(np.float32)
+    else:
+        sdf = np.concatenate([np.zeros(len(x_on)), mesh_distance(far, tri), mesh_distance(near, tri)]).astype(np.float32)
     return x, nrm, sdf.reshape(-1, 1)

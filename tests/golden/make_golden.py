@@ -25,7 +25,7 @@ sys.path.append(REPO)
 sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO] + [REPO]
 
 from src.model import SIREN                                     # noqa: E402  (reference)
-from src.diff_operators import gradient, hessian                # noqa: E402  (reference)
+from src.diff_operators import gradient, hessian, jacobian      # noqa: E402  (reference)
 from src.loss_functions import loss_s1, loss_s2, loss_siren     # noqa: E402  (reference)
 from src.evaluate import evaluate                               # noqa: E402  (reference)
 from src.inverses import inverse                                # noqa: E402  (reference)
@@ -102,6 +102,37 @@ def trajectory(hidden, params, n_pts, steps, lr, mode, weights, dtype, seed):
         hist.append([float(v) for v in terms.values()])
     theta = np.concatenate([p.detach().reshape(-1).double().numpy() for p in model.parameters()])
     return np.array(hist), theta
+
+
+def make_g6():
+    """G6: normals + curvatures at query points the way the sphere tracer derives them (reference
+    src/render_st.py:57-62 `compute_normals_and_cd`, :42-55 `compute_curvature`; that module itself needs open3d,
+    so its few torch lines are issued here against the imported `hessian` / `jacobian` / torch.linalg.eigh)."""
+    out = {}
+    for tag, hid, pseed, n in (("tiny", [32, 32, 32], 11, 48), ("full", [256] * 8, 123, 40)):
+        P = synth.siren_params(hid, seed=pseed, dtype=np.float64)
+        x64 = synth.uniform01(77, 601, 0, 3 * n).reshape(n, 3) * 1.6 - 0.8
+        out[f"{tag}_hidden"] = np.array(hid); out[f"{tag}_param_seed"] = pseed; out[f"{tag}_x"] = x64.astype(np.float32)
+        for dt, dn in ((torch.float64, "f64"), (torch.float32, "f32")):
+            model = ref_model(hid, P, dt)
+            x = torch.from_numpy(x64.astype(np.float32).astype(np.float64)).to(dt)[None]
+            mo = model(x)
+            xin, y = mo["model_in"], mo["model_out"]
+            Hs = hessian(y, xin)                                            # render_st.py:58
+            lam, V = torch.linalg.eigh(Hs)                                  # :59
+            nrm = V[..., 2]                                                 # :60
+            shape_op, status = jacobian(nrm, xin)                           # :43
+            assert status == 0
+            mean = torch.sum(torch.diagonal(shape_op[0], dim1=1, dim2=2), dim=-1) / 2          # :45
+            ext = torch.zeros((shape_op.shape[1], 4, 4), dtype=dt)          # :48-53
+            ext[:, :3, :3] = shape_op[0]
+            ext[:, :3, 3] = nrm[0]
+            ext[:, 3, :3] = nrm[0]
+            gauss = -1 * torch.linalg.det(ext)
+            for k, v in (("H", Hs[0]), ("lam", lam[0]), ("n", nrm[0]), ("pcd", V[0][..., :2]), ("shape_op", shape_op[0]),
+                         ("mean", mean), ("gauss", gauss)):
+                out[f"{tag}_{dn}_{k}"] = v.detach().double().numpy()
+    np.savez_compressed(os.path.join(HERE, "g6_curvature.npz"), **out)
 
 
 def main():
@@ -211,8 +242,12 @@ def main():
     out["surface_points"] = np.array(100000)
     out["batch0_x"] = batches[0][0]; out["batch0_sdf"] = batches[0][2]
     np.savez_compressed(os.path.join(HERE, "g5_beetle.npz"), **out)
+    make_g6()
     print("golden fixtures written to", HERE)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["g6"]:
+        make_g6()
+    else:
+        main()

@@ -237,3 +237,51 @@ def test_extract_fields_and_frames(golden_dir):
     cosang = np.abs((normals[0].cpu().numpy() * V[:, :, 2]).sum(-1))
     gap = lam[:, 2] - lam[:, 1]
     assert cosang[gap > 1e-2 * np.abs(lam).max()].min() > 1 - 1e-4
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_curvature_against_reference(golden_dir, tag):
+    """Row A14 (reference src/render_st.py:42-62): normals, principal directions, shape operator, mean and gaussian
+    curvature at query points, through the reference-named API, against the REFERENCE's fp64 outputs
+    (tests/golden/g6_curvature.npz).  Tolerance 1e-4 (relative max-norm): the reference's own fp32 run differs from
+    its fp64 run by 2.5e-5 on these points; third derivatives amplify rounding by w0^3."""
+    from src.render_st import compute_normals_and_cd, compute_curvature
+    from diffudf_amd import hip_ops as hip
+    G = np.load(os.path.join(golden_dir, "g6_curvature.npz"))
+    hid = list(G[f"{tag}_hidden"])
+    model, P = make_model(hid, int(G[f"{tag}_param_seed"]))
+    x = torch.from_numpy(G[f"{tag}_x"]).to("cuda:0")
+    mo = model(x[None])
+    xin, y = mo["model_in"], mo["model_out"]
+    normals, pcd = compute_normals_and_cd(xin, y)
+    assert normals.shape == (1, len(x), 3) and pcd.shape == (1, len(x), 3, 2) and pcd.device.type == "cpu"
+    mean = compute_curvature(xin, normals, curvature='mean')
+    gauss = compute_curvature(xin, normals, curvature='gaussian')
+    assert compute_curvature(xin, normals, curvature='none') is None
+    assert mean.shape == (1, len(x), 1) and gauss.shape == (1, len(x), 1) and mean.device.type == "cpu"
+    n = normals[0].cpu().numpy().astype(np.float64)
+    sgn = np.sign((n * G[f"{tag}_f64_n"]).sum(1))
+    assert np.abs(np.abs((n * G[f"{tag}_f64_n"]).sum(1)) - 1).max() < 1e-5
+    assert rel(mean[0, :, 0].numpy() * sgn, G[f"{tag}_f64_mean"]) < 1e-4
+    assert rel(gauss[0, :, 0].numpy(), G[f"{tag}_f64_gauss"]) < 1e-4
+    # full shape operator + the mean from the 48-column path, through the C ABI wrapper
+    lam, V, mean3, gauss3, J = hip.query_curvature(model.hip_cfg, model.flat_parameters(), x, want_shape=True, chunk=17)
+    assert rel(J.cpu().numpy() * sgn[:, None, None], G[f"{tag}_f64_shape_op"]) < 1e-4
+    assert rel(mean3.cpu().numpy() * sgn, G[f"{tag}_f64_mean"]) < 1e-4
+    assert rel(lam.cpu().numpy(), G[f"{tag}_f64_lam"]) < 2e-5
+    assert rel(np.abs(np.einsum("nij,nij->nj", V.cpu().numpy()[:, :, :2], G[f"{tag}_f64_pcd"])), np.ones((len(x), 2))) < 1e-4
+    # and against the oracle on other points
+    xo = (synth.uniform01(5, 77, 0, 3 * 200).reshape(200, 3) * 1.8 - 0.9).astype(np.float32)
+    no, _, mo_, go, Jo = O.curvatures(P, xo.astype(np.float64))
+    lam, V, mean3, gauss3, J = hip.query_curvature(model.hip_cfg, model.flat_parameters(), torch.from_numpy(xo).cuda(),
+                                                   want_shape=True)
+    s2 = np.sign((V[:, :, 2].cpu().numpy() * no).sum(1))
+    # ill-conditioned points (nearly equal top eigenvalues) amplify rounding by 1/gap: compare where the gap is sane
+    ok = (lam[:, 2] - lam[:, 1]).cpu().numpy() > 0.05 * np.abs(lam.cpu().numpy()).max()
+    assert ok.sum() > 150
+    assert rel((J.cpu().numpy() * s2[:, None, None])[ok], Jo[ok]) < 2e-4
+    assert rel((mean3.cpu().numpy() * s2)[ok], mo_[ok]) < 2e-4
+    assert rel(gauss3.cpu().numpy()[ok], go[ok]) < 2e-4
+    with pytest.raises(Exception):
+        cfg5 = hip.make_cfg([512] * 2)
+        hip.query_curvature(cfg5, torch.zeros(hip.theta_count(cfg5), device="cuda"), x)

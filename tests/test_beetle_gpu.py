@@ -43,6 +43,34 @@ def test_gpu_sampler_matches_oracle(golden_dir):
     assert a.shape == (1, 2997, 3) and b.shape == (1, 2997, 3) and c.shape == (1, 2997, 1)
 
 
+def test_gpu_sampler_point_cloud_only():
+    """`PointCloud(onlyPCloud=True)` (reference src/dataset.py:80-131): nearest-cloud-point distance for the far
+    stratum (the reference's `shortestDistance`, :72-78, recomputed below in torch exactly as written there), |offset|
+    for the near stratum."""
+    from diffudf_amd.dataset import PointCloud
+    ds = PointCloud(BEETLE, 3000, [0.333, 0.666], 1, device="cuda:0", onlyPCloud=True, seed=11, surfacePoints=5000)
+    assert ds.tri is None
+    pos, pn = ds.pc_pos.cpu().numpy(), ds.pc_nrm.cpu().numpy()
+    x, nrm, sdf = ds.sample(2)
+    xo, no, so = SO.sample_batch(None, pos, pn, 999, 999, 999, seed=11, step=2)
+    assert np.abs(x.cpu().numpy() - xo).max() < 1e-6 and np.array_equal(nrm.cpu().numpy(), no)
+    assert np.abs(sdf.cpu().numpy() - so[:, 0]).max() < 2e-6
+    P, X = x[999:1998].double().cpu(), ds.pc_pos.double().cpu()
+    sq = (X * X).sum(1).repeat(P.shape[0], 1) - 2 * (P @ X.T)                  # reference :73-78, in fp64
+    ref = torch.sqrt(sq.min(dim=1)[0] + (P * P).sum(1))
+    assert np.abs(sdf[999:1998].cpu().numpy() - ref.numpy()).max() < 2e-6
+    # near stratum: the stored distance is the displacement along the unit normal
+    k = np.linalg.norm(x[1998:].cpu().numpy()[:, None, :] - pos[None], axis=2).min(1)
+    assert (k <= sdf[1998:].cpu().numpy() + 1e-6).all()
+    # sharding keeps the union independent of the world size
+    parts = [PointCloud(BEETLE, 3000, [0.333, 0.666], 1, device="cuda:0", onlyPCloud=True, seed=11, surfacePoints=5000,
+                        rank=r, world=2).sample(2) for r in range(2)]
+    got = torch.cat([torch.cat([parts[0][2][:499], parts[1][2][:500]]),
+                     torch.cat([parts[0][2][499:998], parts[1][2][500:1000]]),
+                     torch.cat([parts[0][2][998:], parts[1][2][1000:]])])
+    assert torch.equal(got, sdf)
+
+
 @pytest.mark.parametrize("name,w", [("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])])
 def test_beetle_training_follows_reference(golden_dir, name, w):
     """Loss after N steps on the beetle mesh within 1e-4 (relative) of the reference (north star); with the

@@ -20,3 +20,40 @@ def test_sincos_absolute_error():
     xs = x.astype(np.float64)
     assert np.abs(s - np.sin(xs)).max() < 1.2e-7
     assert np.abs(c - np.cos(xs)).max() < 1.2e-7
+
+
+def test_siren_init_distributions_and_state_dict_layout():
+    """Row A1 (reference src/model.py:7-19, 85-113): first layer ~U(+-1/fan_in), the rest ~U(+-sqrt(6/fan_in)/w0), biases
+    nn.Linear's default U(+-1/sqrt(fan_in)); state_dict keys `net.{i}.0.weight|bias`; the parameters are views of
+    ONE flat buffer in state_dict order (the C ABI's theta)."""
+    import math
+    import torch
+    from diffudf_amd.model import SIREN
+    from diffudf_amd import synth
+    torch.manual_seed(0)
+    m = SIREN(3, 1, [256] * 8, w0=30)
+    keys = list(m.state_dict().keys())
+    assert keys == [f"net.{i}.0.{k}" for i in range(9) for k in ("weight", "bias")]
+    assert sum(p.numel() for p in m.parameters()) == 461825
+    b_hid = math.sqrt(6.0 / 256) / 30
+    for i, blk in enumerate(m.net):
+        w, b = blk[0].weight, blk[0].bias
+        fan = w.shape[1]
+        bound = 1.0 / 3 if i == 0 else b_hid
+        assert w.abs().max() <= bound and w.abs().max() > 0.9 * bound
+        if w.numel() > 1000:                                  # uniform: std = bound/sqrt(3), mean 0
+            assert abs(float(w.std()) * math.sqrt(3) / bound - 1) < 0.02 and abs(float(w.mean())) < 0.02 * bound
+        assert b.abs().max() <= 1 / math.sqrt(fan) + 1e-7
+    flat = m.flat_parameters()
+    off = 0
+    for p in m.parameters():
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    # the build's deterministic generator (what golden fixtures and bench.py use) follows the same distributions
+    P = synth.siren_params([256] * 8, seed=123)
+    assert abs(P[0][0]).max() <= 1 / 3 and abs(P[3][0]).max() <= b_hid and abs(P[3][1]).max() <= 1 / 16
+    assert abs(np.std(P[3][0]) * math.sqrt(3) / b_hid - 1) < 0.02
+    sd = {k: torch.from_numpy(a) for (wt, b), i in zip(P, range(9)) for k, a in
+          ((f"net.{i}.0.weight", wt), (f"net.{i}.0.bias", b))}
+    m.load_state_dict(sd)
+    assert np.array_equal(m.flat_parameters().numpy(), synth.flatten_params(P))

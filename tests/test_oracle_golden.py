@@ -139,3 +139,23 @@ def test_g4_query_and_inverse(golden_dir):
     assert rel(g, G["gradients"]) < 5e-5
     assert rel(H, G["hessians"]) < 1e-4
     assert np.allclose(O.inv_tanh(np.abs(G["values"]), 100), G["inv_tanh"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_curvature_oracle_against_reference(golden_dir, tag):
+    """Row A14: shape operator / mean / gaussian curvature of the top-eigenvector field (reference
+    src/render_st.py:42-62, `jacobian` src/diff_operators.py:214-227) from the oracle's third-derivative tensor.  The
+    reference stores its jacobian in fp32 even when run in fp64 (`torch.zeros(...)` default dtype), hence 2e-7."""
+    G = np.load(os.path.join(golden_dir, "g6_curvature.npz"))
+    hid = list(G[f"{tag}_hidden"])
+    P = synth.siren_params(hid, seed=int(G[f"{tag}_param_seed"]), dtype=np.float64)
+    x = G[f"{tag}_x"].astype(np.float64)
+    n, pcd, mean, gauss, J = O.curvatures(P, x)
+    sgn = np.sign((n * G[f"{tag}_f64_n"]).sum(1))
+    assert np.abs(np.abs((n * G[f"{tag}_f64_n"]).sum(1)) - 1).max() < 1e-9
+    assert rel(J * sgn[:, None, None], G[f"{tag}_f64_shape_op"]) < 2e-7
+    assert rel(mean * sgn, G[f"{tag}_f64_mean"]) < 2e-7
+    assert rel(gauss, G[f"{tag}_f64_gauss"]) < 2e-7
+    # symmetric trilinear form: T is invariant under index permutations
+    T = O.third_derivatives(P, x[:4])
+    assert np.abs(T - np.transpose(T, (0, 2, 1, 3))).max() == 0 and np.abs(T - np.transpose(T, (0, 3, 2, 1))).max() == 0

@@ -56,3 +56,19 @@ def test_sampler_is_shardable_and_deterministic():
     assert (full[2][:99] == 0).all() and (full[2][99:] > 0).all() and (full[1][99:] == 0).all()
     near_d = full[2][99 + 50:, 0]
     assert near_d.max() < 0.06 and np.median(near_d) < 0.02           # |N(0, 0.01)| along the normal
+
+
+def test_point_cloud_only_oracle_matches_reference_formula():
+    """Reference src/dataset.py:72-78 computes sqrt(min(|X|^2 - 2 P.X) + |P|^2); the oracle uses min |P - X|."""
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-0.9, 0.9, (700, 3)).astype(np.float32)
+    Nn = rng.normal(size=(700, 3)); Nn = (Nn / np.linalg.norm(Nn, axis=1, keepdims=True)).astype(np.float32)
+    x, nrm, sdf = SO.sample_batch(None, X, Nn, 40, 50, 60, seed=5, step=1)
+    P = x[40:90].astype(np.float64); Xd = X.astype(np.float64)
+    ref = np.sqrt(((Xd * Xd).sum(1)[None] - 2 * P @ Xd.T).min(1) + (P * P).sum(1))
+    assert np.abs(sdf[40:90, 0] - ref).max() < 1e-6
+    assert (sdf[:40] == 0).all() and (nrm[40:] == 0).all()
+    # near: displaced along the unit normal by `off`, stored distance |off| ~ N(0, 0.01)
+    assert 0.003 < sdf[90:, 0].mean() < 0.02
+    parts = [SO.sample_batch(None, X, Nn, 40, 50, 60, seed=5, step=1, rank=r, world=3) for r in range(3)]
+    assert sum(len(p[0]) for p in parts) == 150
