@@ -1,6 +1,7 @@
 // C-ABI glue: argument checks, workspace layout, kernel sequencing.  See include/dudf_hip.h.
 #include "dudf_internal.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -33,6 +34,12 @@ void dudf_prof_end(int slot, hipStream_t st) {
 
 namespace {
 
+// DUDF_SWEEP=f32 keeps every sweep on the f32-input MFMA kernel (A/B testing); default: bf16x6 where it is built
+bool use_bf16_sweeps() {
+    static const bool on = [] { const char* e = getenv("DUDF_SWEEP"); return !(e && e[0] == 'f'); }();
+    return on;
+}
+
 int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
     if (!ws || bytes < lo.total_bytes || (reinterpret_cast<uintptr_t>(ws) & 15)) return DUDF_E_WORKSPACE;
     if (lo.np > (1ll << 26)) return DUDF_E_BADCFG;          // 32-bit lane offsets inside a stash layer
@@ -42,6 +49,8 @@ int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
 SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     SweepArgs a;
     a.theta = theta; a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt;
+    a.wimg_f = reinterpret_cast<const char*>(ws + lo.ws_wimg);
+    a.wimg_t = a.wimg_f + (size_t)(lo.L - 1) * lo.H * lo.H * 6;
     a.x4 = ws + lo.ws_x4; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
     a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.ZS = ws + lo.ws_ZS; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R;
     a.E = ws + lo.ws_E; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z;
@@ -62,7 +71,9 @@ int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
     }
     if (lo.ncol_n > 0) {
         a.tile0 = (int)(lo.ncol_h / DUDF_TILE_PTS); a.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); a.hess = 0;
-        if ((rc = dudf_launch_sweep(base, lo.H, a, st))) return rc;
+        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base, lo.H, lo.L)) rc = dudf_launch_sweep_bf16(base, lo.H, a, st);
+        else rc = dudf_launch_sweep(base, lo.H, a, st);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -89,6 +100,7 @@ int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, s
 int forward_common(Ctx& c, const float* theta, const float* x, int train, bool reverse) {
     int rc;
     if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
+    if (use_bf16_sweeps() && c.lo.ncol_n > 0 && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
     if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     a.store_s = 1; a.store_c = 1; a.train = train;

@@ -7,7 +7,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define DUDF_TILE_PTS 64           // columns per workgroup pass of a sweep kernel (4 waves x 16)
+#define DUDF_TILE_PTS 64           // columns per workgroup pass of the f32 sweep kernel (4 waves x 16)
+#define DUDF_COL_PAD 128           // column ranges are padded to this: the bf16 sweep kernel's pass (8 waves x 16)
 #define DUDF_NACC 16               // doubles in the reduction scratch
 
 // Everything is in units of floats unless it says bytes.
@@ -22,12 +23,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //     matmuls are linear, so tangents are just more columns of the same MFMAs; only the elementwise tails couple
 //     the four lanes of a quad (DPP quad broadcasts / sums).
 //   column ranges: [0, ncol_h) Hessian quads of the first n_h points, [ncol_h, ncol_h + ncol_n) plain columns of
-//   the remaining n - n_h points; both padded to whole 64-column tiles with zero columns.
+//   the remaining n - n_h points; both padded to whole 128-column tiles with zero columns.
 //
 // workspace:
 //   w1b    [H][4]      = [W_1 | b_1]        A-operand of the first layer (bias folded in as k=3)
 //   w1t16  [16][H]     rows 0..2 = W_1^T, rest 0: A-operand of the last reverse step (df/dx)
-//   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps
+//   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps (f32 kernel)
+//   wimg   bf16x3 images of W_l, then of W_l^T, in A-fragment order (dudf_sweep_bf16.hip)
 //   per column: x4 [np][4] = layer-1 B operand (x,1 | e_k,0), y [np], g [np][4] (a_0 rows), ybar [np], gbar [np][4]
 //   stash arrays, each [L][H/4][np][4]:  element (layer li, feature f, column p) lives at
 //       ((li*(H/4) + f/4)*np + p)*4 + f%4
@@ -48,7 +50,7 @@ struct DudfLayout {
     // theta
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
-    int64_t ws_w1b, ws_w1t16, ws_wt, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
+    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
     int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array
     size_t total_bytes;
@@ -61,11 +63,11 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     if (n < 0 || n_h < 0 || n_h > n) return DUDF_E_BADCFG;
     lo->H = H; lo->L = L; lo->w0 = cfg->w0;
     lo->n = n; lo->n_h = n_h;
-    auto pad = [](int64_t c) { return (c + DUDF_TILE_PTS - 1) / DUDF_TILE_PTS * DUDF_TILE_PTS; };
+    auto pad = [](int64_t c) { return (c + DUDF_COL_PAD - 1) / DUDF_COL_PAD * DUDF_COL_PAD; };
     lo->ncol_h = pad(4 * n_h);
     lo->ncol_n = pad(n - n_h);
     lo->np = lo->ncol_h + lo->ncol_n;
-    if (lo->np == 0) { lo->ncol_n = DUDF_TILE_PTS; lo->np = DUDF_TILE_PTS; }
+    if (lo->np == 0) { lo->ncol_n = DUDF_COL_PAD; lo->np = DUDF_COL_PAD; }
     lo->off_w1 = 0; lo->off_b1 = 3 * (int64_t)H;
     lo->off_hid = 4 * (int64_t)H; lo->hid_stride = (int64_t)H * H + H;
     lo->off_wo = lo->off_hid + (L - 1) * lo->hid_stride; lo->off_bo = lo->off_wo + H;
@@ -75,6 +77,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_w1b = take(4 * (int64_t)H);
     lo->ws_w1t16 = take(16 * (int64_t)H);
     lo->ws_wt = take((int64_t)(L - 1) * H * H);
+    lo->ws_wimg = take((int64_t)(L - 1) * H * H * 3);      // bf16x3 images of W_l and W_l^T: 2 x 6 bytes per weight
     lo->ws_x4 = take(4 * lo->np);
     lo->ws_y = take(lo->np); lo->ws_g = take(4 * lo->np);
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
@@ -96,6 +99,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
 // ---- launchers implemented in the .hip translation units -------------------------------------
 struct SweepArgs {
     const float* theta; const float* w1b; const float* w1t16; const float* wt;
+    const char* wimg_f; const char* wimg_t;   // bf16x3 weight images (forward / transposed), dudf_sweep_bf16.hip
     const float* x4;          // [np][4]: layer-1 B operand per column
     float* y; float* g;       // [np], [np][4]
     const float* ybar; const float* gbar;
@@ -114,6 +118,10 @@ enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,
        SWEEP_FWD_J = 8 };                                                              // third-order jets (query)
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
+// the same sweeps on the bf16 matrix cores at fp32 accuracy (plain columns, H = 256)
+bool dudf_sweep_bf16_supported(int which, int H, int L);
+int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st);
+int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st);

@@ -20,13 +20,10 @@
 //   * what a later sweep needs (s_l, c_l, q_l, r_l/e_l, A_l, zbar_l) is stashed in HBM as one aligned
 //     16-byte store per lane and tile ([layer][feature/4][point][4]); the same arrays are the operands of
 //     the weight-gradient GEMM (dudf_wgrad.hip).
-#include "dudf_internal.h"
-#include "dudf_math.h"
+#include "dudf_sweep_common.h"
 
 namespace {
 
-constexpr int NW = 4;                             // waves per workgroup (one per SIMD); two workgroups share a CU
-constexpr int TILE = NW * 16;                     // points per workgroup pass
 
 template <int H>
 struct Geo {
@@ -41,9 +38,6 @@ struct Geo {
     static constexpr int NSTG = DMA ? 1 : (F4 + NTHR - 1) / NTHR;
 };
 
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 
 // ---- weight chunk staging: rows [32r, 32r+32) of a row-major HxH matrix -> LDS buffer with padded rows -----
 // H == 256: LDS-DMA (global_load_lds_dwordx4): each wave-instruction moves one whole 1 KiB row, so the rows
@@ -100,226 +94,11 @@ __device__ __forceinline__ void stage_commit(float* buf, const f32x4 (&stg)[Geo<
     }
 }
 
-// Stash addressing: `ub` is a WAVE-UNIFORM float offset (layer and tile folded in, lives in SGPRs),
-// `vo` the lane's 32-bit float offset ((quarter*np + point)*4): global_load/store take the saddr form
-// and no per-tile 64-bit address is kept in VGPRs.
-#define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>((arr) + (ub) + (vo))
-#define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>((arr) + (ub) + (vo))
-
-// ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
-__device__ __forceinline__ float quad_bcast0(float v) {          // value of the quad's lane 0 (the value channel)
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x00, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad_sum(float v) {             // sum over the quad, in every lane
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-    return v;
-}
-
-constexpr bool is_hess(int SW) { return SW >= 4; }      // channels that are not all "value" columns (quads, jets)
-constexpr bool is_jet(int SW) { return SW == SWEEP_FWD_J; }
-constexpr int base_of(int SW) { return SW & 3; }
-
-// Elementwise tail of one 16-feature x 16-column tile.
-// FL (compile-time, so the tail stays one basic block that can be interleaved with MFMAs):
-//   SWEEP_FWD: bit0 = stash s_l, bit1 = stash c_l;  SWEEP_REV: bit0 = training (stash q_l, r_l);
-//   SWEEP_ADJ_REV: bit0 = e_l exists (df/dx terms present)
-//   Hessian variants: SWEEP_FWD_H / SWEEP_REV_H bit0 = training; the adjoint ones ignore FL.
-// Hessian quads (lane&3 = channel, 0 = value, 1+k = d/dx_k):
-//   FWD_H      z|zdot^k        -> h = s | hdot^k = w0 c zdot^k                      stash C = c, ZS = s|zdot^k, S = out
-//   REV_H      a|adot^k        -> q = w0 c a | qdot^k = w0(-w0 s zdot^k a + c adot^k)   stash Q = out, R = a|adot^k
-//   ADJ_FWD_H  Q|Qdot^k        -> A = w0 c Q + w0 sum_k cdot^k Qdot^k | Adot^k = w0 c Qdot^k          stash A = out,
-//              E = w0 c sbar_rev - w0 s cbar_rev | zdotbar_rev^k = -w0 s chat^k, chat^k = w0 a Qdot^k,
-//              cbar_rev = w0 a Q + w0 sum_k adot^k Qdot^k, sbar_rev = -w0 sum_k zdot^k chat^k
-//   ADJ_REV_H  hbar|hdotbar^k  -> zbar = E + w0 c hbar - w0^2 s sum_k zdot^k hdotbar^k | zdotbar^k = E + w0 c hdotbar^k
-// Third-order jets (SWEEP_FWD_J, query only, nothing stashed): a 16-column tile is ONE point — its columns carry the
-// Taylor coefficients of  (s,r,t) -> z(x + s A + r B + t C)  for the monomials
-//   0: 1 | 1: s  2: r  3: t | 4: ss  5: rr  6: tt  7: sr  8: st  9: rt | 10: sst  11: rrt  12: srt  13: stt  14: rtt | 15: 0
-// (A, B, C = the three direction columns of x4).  The matmuls act on every coefficient alike; the sine composes them:
-// with u = w0 (z - z_0), sin(w0 z) = s + c u - s u^2/2 - c u^3/6 + ..., i.e. for monomial m
-//   h_m = c U_m - s [m](u^2/2) - c [m](u^3/6),     U_m = w0 z_m
-// e.g. [ss] = U_s^2/2, [st] = U_s U_t, [sst](u^2/2) = U_ss U_t + U_s U_st, [sst](u^3/6) = U_s^2 U_t/2,
-// [srt](u^2/2) = U_sr U_t + U_st U_r + U_rt U_s, [srt](u^3/6) = U_s U_r U_t.  kJetLane packs, per monomial, which
-// lanes of the 16-group feed those products.  2 y_sst = d^3 f[A,A,C] etc. are the mixed third derivatives the
-// curvature of the Hessian's eigenvector field needs (reference src/render_st.py:42-55), without the cancellation a
-// polarisation of pure directional derivatives would suffer.
-// word: bits 0-3/4-7/8-11 second-order source lanes (15 = the zero column), 12-13/14-15/16-17 the first-order factor
-// paired with each, 18-19/20-21/22-23 factors a,b,c of the pure first-order product, 24-25 weight of F_a F_b in u^2/2
-// (0, 1 = 1/2, 2 = 1), 26-27 weight of F_a F_b F_c in u^3/6, bit 28: value column.
-constexpr unsigned jet_word(int sl0, int f0, int sl1, int f1, int sl2, int f2, int a, int b, int c, int w2, int w3,
-                            int isval = 0) {
-    return (unsigned)sl0 | ((unsigned)sl1 << 4) | ((unsigned)sl2 << 8) | ((unsigned)f0 << 12) | ((unsigned)f1 << 14) |
-           ((unsigned)f2 << 16) | ((unsigned)a << 18) | ((unsigned)b << 20) | ((unsigned)c << 22) |
-           ((unsigned)w2 << 24) | ((unsigned)w3 << 26) | ((unsigned)isval << 28);
-}
-__constant__ unsigned kJetLane[16] = {
-    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0, 1),                                   // value
-    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0), jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0),
-    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0),                                      // s, r, t
-    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 1, 0), jet_word(15, 0, 15, 0, 15, 0, 1, 1, 0, 1, 0),   // ss, rr
-    jet_word(15, 0, 15, 0, 15, 0, 2, 2, 0, 1, 0), jet_word(15, 0, 15, 0, 15, 0, 0, 1, 0, 2, 0),   // tt, sr
-    jet_word(15, 0, 15, 0, 15, 0, 0, 2, 0, 2, 0), jet_word(15, 0, 15, 0, 15, 0, 1, 2, 0, 2, 0),   // st, rt
-    jet_word(4, 2, 8, 0, 15, 0, 0, 0, 2, 0, 1),                                        // sst: ss*t + st*s ; s s t / 2
-    jet_word(5, 2, 9, 1, 15, 0, 1, 1, 2, 0, 1),                                        // rrt: rr*t + rt*r ; r r t / 2
-    jet_word(7, 2, 8, 1, 9, 0, 0, 1, 2, 0, 2),                                         // srt: sr*t + st*r + rt*s ; s r t
-    jet_word(6, 0, 8, 2, 15, 0, 2, 2, 0, 0, 1),                                        // stt: tt*s + st*t ; t t s / 2
-    jet_word(6, 1, 9, 2, 15, 0, 2, 2, 1, 0, 1),                                        // rtt: tt*r + rt*t ; t t r / 2
-    jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0)};                                     // spare: stays zero
-
-template <int SW, int FL>
-__device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
-                                          unsigned vo, bool isv) {
-    f32x4 out;
-    if constexpr (SW == SWEEP_FWD) {
-        f32x4 s, c;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float sv, cv;
-            dudf_sincos(a.w0 * acc[t], &sv, &cv);
-            s[t] = sv; c[t] = cv;
-        }
-        if constexpr (FL & 1) *DUDF_AT(a.S, ub, vo) = s;
-        if constexpr (FL & 2) *DUDF_AT(a.C, ub, vo) = c;
-        out = s;
-    } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
-        out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
-        if constexpr (FL & 1) {
-            *DUDF_AT(a.Q, ub, vo) = out;
-            *DUDF_AT(a.R, ub, vo) = (a.w0 * a.w0) * o2 * acc;   // r_l = w0^2 s_l a_l
-        }
-    } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
-        out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
-        *DUDF_AT(a.A, ub, vo) = out;
-        *DUDF_AT(a.E, ub, vo) = o2 * acc;            // e_l = r_l Q_l
-    } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
-        out = a.w0 * o1 * acc - o2;                  // zbar_l
-        *DUDF_AT(a.Z, ub, vo) = out;
-    } else if constexpr (SW == SWEEP_FWD_H) {
-        f32x4 c, zs;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float sv, cv;
-            dudf_sincos(a.w0 * quad_bcast0(acc[t]), &sv, &cv);
-            c[t] = cv;
-            zs[t] = isv ? sv : acc[t];
-            out[t] = isv ? sv : a.w0 * cv * acc[t];
-        }
-        *DUDF_AT(a.C, ub, vo) = c;
-        *DUDF_AT(a.ZS, ub, vo) = zs;
-        if constexpr (FL & 1) *DUDF_AT(a.S, ub, vo) = out;
-    } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float sv = quad_bcast0(o2[t]), a0 = quad_bcast0(acc[t]);
-            out[t] = isv ? a.w0 * o1[t] * acc[t] : a.w0 * (o1[t] * acc[t] - a.w0 * sv * o2[t] * a0);
-        }
-        if constexpr (FL & 1) {
-            *DUDF_AT(a.Q, ub, vo) = out;
-            *DUDF_AT(a.R, ub, vo) = acc;
-        }
-    } else if constexpr (SW == SWEEP_ADJ_FWD_H) {    // o1 = c, o2 = s|zdot^k, o3 = a|adot^k
-        f32x4 e;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float sv = quad_bcast0(o2[t]), a0 = quad_bcast0(o3[t]);
-            const float cdot = -a.w0 * sv * o2[t];
-            const float chat = a.w0 * a0 * acc[t];
-            const float s1 = quad_sum(isv ? 0.f : cdot * acc[t]);
-            const float s2 = quad_sum(isv ? 0.f : o3[t] * acc[t]);
-            const float s3 = quad_sum(isv ? 0.f : o2[t] * chat);
-            const float cbar = a.w0 * (o3[t] * acc[t] + s2);
-            const float sbar = -a.w0 * s3;
-            out[t] = a.w0 * (o1[t] * acc[t] + (isv ? s1 : 0.f));
-            e[t] = isv ? a.w0 * (o1[t] * sbar - sv * cbar) : -a.w0 * sv * chat;
-        }
-        *DUDF_AT(a.A, ub, vo) = out;
-        *DUDF_AT(a.E, ub, vo) = e;
-    } else if constexpr (SW == SWEEP_FWD_J) {
-        const int lane = threadIdx.x & 63, l0 = lane & 48;
-        const unsigned jw = kJetLane[lane & 15];
-        const float w2 = 0.5f * (float)((jw >> 24) & 3), w3 = 0.5f * (float)((jw >> 26) & 3);
-        const bool isval = (jw >> 28) & 1;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float sv, cv;
-            dudf_sincos(a.w0 * __shfl(acc[t], l0), &sv, &cv);
-            const float F[3] = {a.w0 * __shfl(acc[t], l0 + 1), a.w0 * __shfl(acc[t], l0 + 2), a.w0 * __shfl(acc[t], l0 + 3)};
-            auto sel = [&](unsigned k) -> float { k &= 3; return k == 0 ? F[0] : (k == 1 ? F[1] : F[2]); };
-            const float S0 = a.w0 * __shfl(acc[t], l0 + (int)(jw & 15)), S1 = a.w0 * __shfl(acc[t], l0 + (int)((jw >> 4) & 15)),
-                        S2 = a.w0 * __shfl(acc[t], l0 + (int)((jw >> 8) & 15));
-            const float fab = sel(jw >> 18) * sel(jw >> 20);
-            const float p2 = S0 * sel(jw >> 12) + S1 * sel(jw >> 14) + S2 * sel(jw >> 16) + w2 * fab;
-            const float p3 = w3 * fab * sel(jw >> 22);
-            out[t] = isval ? sv : cv * (a.w0 * acc[t] - p3) - sv * p2;
-        }
-    } else {                                         // SWEEP_ADJ_REV_H: o1 = c, o2 = s|zdot^k, o3 = E
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float sv = quad_bcast0(o2[t]);
-            const float st = quad_sum(isv ? 0.f : o2[t] * acc[t]);
-            out[t] = o3[t] + a.w0 * o1[t] * acc[t] - (isv ? a.w0 * a.w0 * sv * st : 0.f);
-        }
-        *DUDF_AT(a.Z, ub, vo) = out;
-    }
-    return out;
-}
-
-template <int SW, int FL>
-__device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, unsigned vo, f32x4& o1, f32x4& o2,
-                                               f32x4& o3) {
-    o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
-    if constexpr (SW == SWEEP_REV) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = *DUDF_CAT(a.S, ub, vo);
-    } else if constexpr (SW == SWEEP_ADJ_FWD) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.R, ub, vo);
-    } else if constexpr (SW == SWEEP_ADJ_REV) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = *DUDF_CAT(a.E, ub, vo);            // no df/dx terms (loss_s2): e_l == 0
-    } else if constexpr (SW == SWEEP_REV_H) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.ZS, ub, vo);
-    } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.ZS, ub, vo);
-        o3 = *DUDF_CAT(a.R, ub, vo);
-    } else if constexpr (SW == SWEEP_ADJ_REV_H) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.ZS, ub, vo);
-        o3 = *DUDF_CAT(a.E, ub, vo);
-    }
-}
-
-// The LDS-DMA pieces this wave issued have landed.  vmcnt counts every vector-memory operation of the wave in
-// issue order, and the asm statements pin that order: after the DMA pieces of a chunk come exactly
-// younger_ops<SW,FL>() compiler-issued operations (operand loads of the next tail + stash stores of the current
-// one), so waiting for "all but that many" retires the DMA while those stay in flight.
-// tests/test_isa_contract.py counts the instructions in the built code object and fails if this drifts.
-template <int SW, int FL>
-constexpr int younger_ops() {
-    return SW == SWEEP_FWD ? 2 + 2 * ((FL & 1) + ((FL >> 1) & 1))      // 2 bias loads + s/c stores of 2 tiles
-         : SW == SWEEP_REV ? ((FL & 1) ? 4 + 4 : 2)                     // c,s loads + q,r stores | c loads
-         : SW == SWEEP_ADJ_FWD ? 4 + 4                                  // c,r loads + A,e stores
-         : SW == SWEEP_ADJ_REV ? ((FL & 1) ? 4 + 2 : 2 + 2)             // c(,e) loads + zbar stores
-         : SW == SWEEP_FWD_H ? 2 + 2 * (2 + (FL & 1))                   // bias + C,ZS(,S) stores
-         : SW == SWEEP_REV_H ? 4 + ((FL & 1) ? 4 : 0)                   // c,zs loads + Q,R stores
-         : SW == SWEEP_ADJ_FWD_H ? 6 + 4                                // c,zs,aa loads + A,E stores
-         : SW == SWEEP_FWD_J ? 2                                        // bias loads only
-         : 6 + 2;                                                       // c,zs,E loads + Z stores
-}
 template <int H, int N>
 __device__ __forceinline__ void dma_wait() {
     if constexpr (Geo<H>::DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-// Two finished accumulator tiles whose elementwise tail has not run yet.  The tail of chunk r-1 is executed in
-// the middle of chunk r's MFMA stream (same basic block), so sin/cos, stash traffic and MFMAs overlap inside
-// one wave instead of serialising at every chunk barrier.
-struct Pending {
-    f32x4 acc0, acc1, o1a, o2a, o3a, o1b, o2b, o3b;
-    int64_t ub0, ub1;
-};
 
 // One sweep over one 64-column tile.  `seed` replaces the per-column operand the prologue would read from HBM when
 // the caller already has it in registers (fused step kernel: gbar[q] for SWEEP_ADJ_FWD, ybar for SWEEP_ADJ_REV);

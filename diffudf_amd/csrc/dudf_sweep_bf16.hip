@@ -1,0 +1,394 @@
+// The four plain-column SIREN sweeps on the bf16 matrix cores at fp32 accuracy ("bf16x6", gfx950 / CDNA4).
+//
+// Same sweeps, same tails, same stash as dudf_sweep.hip (see there for what each sweep computes and which reference
+// lines it replaces); what changes is how a hidden layer  OUT[feature][column] = M[feature][k] * IN[k][column]  is
+// multiplied.  Every fp32 operand is split EXACTLY into three bf16 pieces v = h + m + l (8+8+8 significand bits,
+// round-to-nearest at each step so the three pieces always hold all 24 bits); a product is the six partial products
+// whose weight is >= 2^-16 (hh, hm, mh, hl, lh, mm — the dropped ml, lm, ll are below fp32 rounding), accumulated in
+// fp32 by v_mfma_f32_16x16x32_bf16.  Six of those (16 cycles each, K = 32) replace eight v_mfma_f32_16x16x4_f32
+// (32 cycles each, K = 4): 96 instead of 256 matrix-core cycles per 16x16 tile and 32 features.
+//
+// Mapping (output-stationary, K streamed):
+//   * a wave owns 16 columns for a whole sweep; a workgroup is 8 waves = 128 columns, two waves per SIMD, one
+//     workgroup per CU.  The accumulator tile of v_mfma_f32_16x16x32_bf16 has the layout of the f32 instruction
+//     (row = 4*(lane>>4)+reg = feature, col = lane&15 = column), so all tails are shared (dudf_sweep_common.h) and the
+//     stash layout is unchanged.
+//   * a layer keeps ALL its 16 output tiles in accumulators (64 registers) and streams over the 8 k-blocks of 32
+//     input features.  The B operand of k-block kb wants, per lane, 8 k of one column (k = 8*(lane>>4) + e).  K is a
+//     contraction index, so a permutation applied to both operands is free: k-slot (g, e) is mapped to feature
+//     32kb + 4g + e (e < 4) or 32kb + 16 + 4g + (e-4) — exactly the 4+4 accumulator registers a lane holds of tiles
+//     2kb and 2kb+1 of the PREVIOUS layer.  So step kb runs the elementwise tail (bias, sin/cos or the adjoint
+//     formulas, stash stores) of those two tiles of the previous layer, splits the 8 results into pieces and packs
+//     them (v_cvt_pk_bf16_f32) into 12 registers: the B operand, used at once by 16 tiles x 6 MFMAs and then dead.
+//     Activations never touch LDS, and the tail of step kb+1 overlaps the MFMAs of step kb inside a wave.
+//   * the weights are pre-split once per step (pack kernel below) into an image in A-FRAGMENT ORDER: for every
+//     (k-block, 16-row tile, piece) the 1 KiB that one ds_read_b128 wave-instruction fetches, lane L = (g<<4 | m)
+//     holding M[row m][the 8 features of k-slots (g, 0..7)].  The 48 KiB of a k-block (16 tiles x 3 pieces at H = 256)
+//     are contiguous, so LDS-DMA moves them verbatim in 1 KiB wave-instructions and the reads are lane-linear:
+//     conflict-free without padding or swizzle.  Double buffered (96 KiB), one barrier per k-block, hand-counted
+//     vmcnt as in the f32 kernel.  128 columns share every byte fetched from L2: at bf16 rates the f32 kernel's
+//     64-column workgroups would be bound by L2 -> LDS weight traffic, not by the matrix cores.
+//   * the first layer (K = 3+1) and the output / df/dx matmuls stay on the fp32 MFMA.
+#include "dudf_sweep_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NWB = 8;                                 // waves per workgroup: two per SIMD
+constexpr int TILEB = NWB * 16;                        // columns per workgroup pass
+
+template <int H>
+struct GeoB {
+    static constexpr int NT = H / 16;                  // 16-feature tiles per activation vector
+    static constexpr int NKB = H / 32;                 // 32-feature k-blocks = weight chunks per layer
+    static constexpr int FRAG = 1024;                  // bytes of one A fragment: 64 lanes x 8 bf16
+    static constexpr int CHUNKB = NT * 3 * FRAG;       // one k-block of a matrix: [tile][piece]
+    static constexpr int IMGB = NKB * CHUNKB;          // one matrix: 6 bytes per weight
+    static constexpr int NDMA = NT * 3 / NWB;          // LDS-DMA wave-instructions per wave and chunk
+    static constexpr int NTHR = 64 * NWB;
+};
+
+
+__device__ __forceinline__ f32x4 mfma_b(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk(f32x2 v) {              // one v_cvt_pk_bf16_f32: lo = bf16(v.x), hi = bf16(v.y)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 unpack(unsigned p) {              // the two bf16 back as exact floats
+    return f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+}
+// 8 fp32 values (two accumulator tiles' registers of one lane) -> the three bf16x8 pieces of a B / A operand
+__device__ __forceinline__ void split8(const f32x4 e0, const f32x4 e1, u32x4& h, u32x4& m, u32x4& l) {
+    const f32x2 v[4] = {{e0[0], e0[1]}, {e0[2], e0[3]}, {e1[0], e1[1]}, {e1[2], e1[3]}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned hp = cvt_pk(v[i]);
+        const f32x2 r1 = v[i] - unpack(hp);                        // exact
+        const unsigned mp = cvt_pk(r1);
+        const f32x2 r2 = r1 - unpack(mp);                          // exact
+        h[i] = hp; m[i] = mp; l[i] = cvt_pk(r2);
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x4 as_u(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
+__device__ __forceinline__ f32x4 as_f(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+
+// chunk r of a weight image -> LDS buffer, 1 KiB per wave-instruction (see dudf_sweep.hip for why this is inline asm)
+template <int H>
+__device__ __forceinline__ void dma_issue(const char* __restrict__ chunk, char* buf, int lane, int wave) {
+    using G = GeoB<H>;
+#pragma unroll
+    for (int i = 0; i < G::NDMA; ++i) {
+        const int piece = wave * G::NDMA + i;
+        const char* g = chunk + (size_t)piece * G::FRAG + lane * 16;
+        const unsigned l = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) char*)(buf + piece * G::FRAG));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+    }
+}
+template <int N>
+__device__ __forceinline__ void dma_wait_b() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// vector-memory operations of one step that are younger than its LDS-DMA: the operand loads of the next tail and
+// the stash stores of the current one (tests/test_isa_contract.py counts them in the built code object)
+template <int SW, int FL>
+constexpr int younger_b() {
+    return SW == SWEEP_FWD ? 2 + 2 * ((FL & 1) + ((FL >> 1) & 1))      // 2 bias loads + s/c stores of 2 tiles
+         : SW == SWEEP_REV ? ((FL & 1) ? 4 + 4 : 2)                     // c,s loads + q,r stores | c loads
+         : SW == SWEEP_ADJ_FWD ? 4 + 4                                  // c,r loads + A,e stores
+         : ((FL & 1) ? 4 + 2 : 2 + 2);                                  // SWEEP_ADJ_REV: c(,e) loads + zbar stores
+}
+
+struct TailOps { f32x4 o1a, o2a, o1b, o2b, ba, bb; };   // operands of one pair of tiles (+ bias, forward sweep)
+
+template <int H, int SW, int FL>
+__device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile, char* lds, unsigned& gc) {
+    using G = GeoB<H>;
+    static_assert(!is_hess(SW), "plain columns only");
+    constexpr int BS = base_of(SW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int nhid = a.L - 1;                          // hidden x hidden layers (>= 1 here)
+    constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
+
+    f32x4 acc[G::NT], prev[G::NT];                     // this layer's accumulators / the previous layer's, tails pending
+    const int64_t p = (int64_t)tile * TILEB + wave * 16 + li;
+    auto image = [&](int j) -> const char* {
+        return kFwdDir ? a.wimg_f + (size_t)j * G::IMGB : a.wimg_t + (size_t)(nhid - 1 - j) * G::IMGB;
+    };
+    // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
+    auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
+    auto bias_ptr = [&](int layer) -> const float* {   // forward sweep: b_{layer+1}
+        return layer == 0 ? a.theta + 3 * H : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;
+    };
+    auto stash_base = [&](int layer, int T) -> int64_t {
+        return (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
+    };
+    const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 4);
+    auto load_ops = [&](int layer, int kb, TailOps& o) {
+        f32x4 dummy;
+        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vo, o.o1a, o.o2a, dummy);
+        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vo, o.o1b, o.o2b, dummy);
+        if constexpr (BS == SWEEP_FWD) {
+            o.ba = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 32 * kb + 4 * q);
+            o.bb = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 32 * kb + 16 + 4 * q);
+        }
+    };
+    // tail of tiles 2kb, 2kb+1 of `layer`: fp32 results (and the stash stores the sweep owes)
+    auto run_tail = [&](int layer, int kb, const f32x4 z0, const f32x4 z1, const TailOps& o, f32x4& e0, f32x4& e1) {
+        const f32x4 zero = {0, 0, 0, 0};
+        if constexpr (BS == SWEEP_FWD) {
+            e0 = epilogue<SW, FL>(a, z0 + o.ba, zero, zero, zero, stash_base(layer, 2 * kb), vo, true);
+            e1 = epilogue<SW, FL>(a, z1 + o.bb, zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, true);
+        } else {
+            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, zero, stash_base(layer, 2 * kb), vo, true);
+            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, zero, stash_base(layer, 2 * kb + 1), vo, true);
+        }
+    };
+    auto pin_ops = [&](TailOps& o) {                    // make the compiler wait for these loads HERE
+        if constexpr (BS == SWEEP_FWD) asm volatile("" : "+v"(o.ba), "+v"(o.bb));
+        else asm volatile("" : "+v"(o.o1a), "+v"(o.o2a), "+v"(o.o1b), "+v"(o.o2b));
+    };
+
+    __syncthreads();                                   // every wave is past its last LDS read of the previous tile
+    dma_issue<H>(image(0), lds + (gc & 1) * G::CHUNKB, lane, wave);
+
+    // ------------------------------ first layer (fp32, K = 3): pre-activations / incoming adjoints of 16 tiles -------
+    {
+        float b = 0.f, yb = 1.f;
+        if constexpr (BS == SWEEP_FWD) b = (q < 3) ? a.x4[p * 4 + q] : 0.f;           // bias is added by the tail
+        if constexpr (BS == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;
+        if constexpr (BS == SWEEP_ADJ_REV) yb = a.ybar[p];
+#pragma unroll
+        for (int T = 0; T < G::NT; ++T) {
+            if constexpr (kFwdDir) prev[T] = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
+            else prev[T] = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
+        }
+    }
+
+    // ------------------------------ hidden x hidden layers ------------------------------
+    // Step kb of matrix j:  [operands of tail kb+1 have landed] -> DMA of the next chunk -> operand loads of tail kb+2
+    // -> 16 tiles x 6 MFMAs with B(kb), interleaved with tail kb+1 -> B(kb+1) -> dma_wait + barrier.
+    // No compiler-visible vector-memory wait may sit between a DMA issue and its dma_wait (hipcc does not see the asm
+    // DMA in its vmcnt bookkeeping), hence the pins.
+    TailOps ops_next, ops_cur;                         // in flight for the tail after next / pinned for the next one
+    u32x4 bh, bm, bl;                                  // B operand of the current step
+    load_ops(in_layer(0), 0, ops_cur);
+    load_ops(in_layer(0), 1, ops_next);
+    for (int j = 0; j < nhid; ++j) {
+        const char* M = image(j);
+        const char* Mn = (j + 1 < nhid) ? image(j + 1) : nullptr;
+        const int lin = in_layer(j), lnx = in_layer(j + 1);
+        {   // B(0): tail of the previous layer's tiles 0, 1 — nothing of this layer can start before it
+            f32x4 e0, e1;
+            pin_ops(ops_cur);
+            run_tail(lin, 0, prev[0], prev[1], ops_cur, e0, e1);
+            split8(e0, e1, bh, bm, bl);
+        }
+#pragma unroll
+        for (int T = 0; T < G::NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
+        if (j == 0) dma_wait_b<0>();
+        else dma_wait_b<younger_b<SW, FL>()>();
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < G::NKB; ++kb) {
+            const char* bp = lds + (gc & 1) * G::CHUNKB + lane * 16;
+            auto frag = [&](int T, int pc) -> bf16x8 {
+                return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
+            };
+            // operands of tail kb+1 (loaded one step ago) -> ops_cur; the compiler's wait sits before the DMA issue
+            ops_cur = ops_next;
+            pin_ops(ops_cur);
+            char* nbuf = lds + ((gc + 1) & 1) * G::CHUNKB;
+            if (kb + 1 < G::NKB) dma_issue<H>(M + (size_t)(kb + 1) * G::CHUNKB, nbuf, lane, wave);
+            else if (Mn) dma_issue<H>(Mn, nbuf, lane, wave);
+            // operand loads two tails ahead: (lin, kb+2), or the first two pairs of the next layer's input
+            if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_next);
+            else load_ops(lnx, kb + 2 - G::NKB, ops_next);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 nh, nm, nl;
+            bf16x8 an[3] = {frag(0, 0), frag(0, 1), frag(0, 2)};
+#pragma unroll
+            for (int T = 0; T < G::NT; ++T) {
+                const bf16x8 ah = an[0], am = an[1], al = an[2];
+                if (T + 1 < G::NT) {
+                    an[0] = frag(T + 1, 0); an[1] = frag(T + 1, 1); an[2] = frag(T + 1, 2);
+                    __builtin_amdgcn_sched_barrier(0x7F);
+                }
+                f32x4 c = acc[T];
+                c = mfma_b(am, as_bf(bm), c);                           // smallest terms first
+                c = mfma_b(al, as_bf(bh), c);
+                c = mfma_b(ah, as_bf(bl), c);
+                c = mfma_b(am, as_bf(bh), c);
+                c = mfma_b(ah, as_bf(bm), c);
+                c = mfma_b(ah, as_bf(bh), c);
+                acc[T] = c;
+                if (T == 0 && kb + 1 < G::NKB) {                        // the next step's B operand, between the MFMAs
+                    f32x4 e0, e1;
+                    run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
+                    split8(e0, e1, nh, nm, nl);
+                }
+            }
+            if (kb + 1 < G::NKB) { bh = nh; bm = nm; bl = nl; }
+            ++gc;
+            if (kb + 1 < G::NKB || Mn) {
+                if (kb + 1 < G::NKB) dma_wait_b<younger_b<SW, FL>()>();
+                // (the wait for the next layer's first chunk sits after B(0)'s tail, above)
+            }
+            if (kb + 1 < G::NKB) __syncthreads();
+        }
+#pragma unroll
+        for (int T = 0; T < G::NT; ++T) prev[T] = acc[T];
+    }
+
+    // ------------------------------ tails of the last hidden layer + output stage (fp32) ------------------------------
+    {
+        const int lin = in_layer(nhid);
+        float part = 0.f;
+        f32x4 accg = {0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < G::NKB; ++kb) {
+            f32x4 e0, e1;
+            run_tail(lin, kb, prev[2 * kb], prev[2 * kb + 1], ops_cur, e0, e1);
+            if constexpr (BS == SWEEP_FWD) {
+                const f32x4 w0v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 4 * q);
+                const f32x4 w1v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 16 + 4 * q);
+                part += e0[0] * w0v[0] + e0[1] * w0v[1] + e0[2] * w0v[2] + e0[3] * w0v[3];
+                part += e1[0] * w1v[0] + e1[1] * w1v[1] + e1[2] * w1v[2] + e1[3] * w1v[3];
+            } else if constexpr (BS == SWEEP_REV) {
+                const f32x4 w0v = *reinterpret_cast<const f32x4*>(a.w1t16 + li * H + 32 * kb + 4 * q);
+                const f32x4 w1v = *reinterpret_cast<const f32x4*>(a.w1t16 + li * H + 32 * kb + 16 + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accg = mfma16(w0v[t], e0[t], accg);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accg = mfma16(w1v[t], e1[t], accg);
+            }
+            ops_cur = ops_next;
+            if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_next);
+        }
+        if constexpr (BS == SWEEP_FWD) {
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            part += a.theta[a.off_bo];
+            if (q == 0) a.y[p] = part;
+        } else if constexpr (BS == SWEEP_REV) {
+            if (q == 0) *reinterpret_cast<f32x4*>(a.g + p * 4) = f32x4{accg[0], accg[1], accg[2], 0.f};
+        }
+    }
+}
+
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_b[];
+    unsigned gc = 0;
+    const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;           // this kernel's tiles are 128 columns wide
+    for (int t = blockIdx.x; t < ntb; t += gridDim.x)
+        sweep_tile_b<H, SW, FL>(a, a.tile0 * TILE / TILEB + t, lds_b, gc);
+}
+
+// theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L
+template <int H>
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ theta, char* __restrict__ img_f,
+                                                        char* __restrict__ img_t, int nhid, int64_t off_hid,
+                                                        int64_t hid_stride) {
+    using G = GeoB<H>;
+    const int64_t total = (int64_t)2 * nhid * G::NKB * G::NT * 64;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t v = idx;
+        const int lane = (int)(v & 63); v >>= 6;
+        const int T = (int)(v % G::NT); v /= G::NT;
+        const int kb = (int)(v % G::NKB); v /= G::NKB;
+        const int j = (int)(v % nhid); v /= nhid;
+        const int dir = (int)v;
+        const int m = lane & 15, g = lane >> 4;
+        const int row = 16 * T + m;
+        const float* W = theta + off_hid + (int64_t)j * hid_stride;
+        f32x4 e0, e1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f0 = 32 * kb + 4 * g + e, f1 = f0 + 16;
+            e0[e] = dir == 0 ? W[(int64_t)row * H + f0] : W[(int64_t)f0 * H + row];
+            e1[e] = dir == 0 ? W[(int64_t)row * H + f1] : W[(int64_t)f1 * H + row];
+        }
+        u32x4 h, mm, l;
+        split8(e0, e1, h, mm, l);
+        char* base = (dir == 0 ? img_f : img_t) + (size_t)j * G::IMGB + (size_t)kb * G::CHUNKB + (size_t)T * 3 * G::FRAG + lane * 16;
+        *reinterpret_cast<u32x4*>(base) = h;
+        *reinterpret_cast<u32x4*>(base + G::FRAG) = mm;
+        *reinterpret_cast<u32x4*>(base + 2 * G::FRAG) = l;
+    }
+}
+
+template <int H>
+int launch_b(int which, const SweepArgs& a, hipStream_t st) {
+    using G = GeoB<H>;
+    const size_t smem = 2 * G::CHUNKB;
+    if (a.ntiles <= 0) return 0;
+    const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;
+    int grid = ntb < 256 ? ntb : 256;                  // one resident 8-wave workgroup per CU
+    hipError_t e = hipSuccess;
+#define DUDF_GO_B(SW, FL)                                                                                   \
+    do {                                                                                                    \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_bf16_kernel<H, SW, FL>),           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
+            if (e != hipSuccess) return (int)e;                                                             \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((sweep_bf16_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);         \
+    } while (0)
+    switch (which) {
+        case SWEEP_FWD:
+            if (!(a.store_s && a.store_c)) return DUDF_E_BADMODE;
+            DUDF_GO_B(SWEEP_FWD, 3);
+            break;
+        case SWEEP_REV:
+            if (a.train) DUDF_GO_B(SWEEP_REV, 1); else DUDF_GO_B(SWEEP_REV, 0);
+            break;
+        case SWEEP_ADJ_FWD: DUDF_GO_B(SWEEP_ADJ_FWD, 0); break;
+        case SWEEP_ADJ_REV:
+            if (a.have_e) DUDF_GO_B(SWEEP_ADJ_REV, 1); else DUDF_GO_B(SWEEP_ADJ_REV, 0);
+            break;
+        default: return DUDF_E_UNSUPPORTED;
+    }
+#undef DUDF_GO_B
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool dudf_sweep_bf16_supported(int which, int H, int L) {
+    return H == 256 && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV;
+}
+
+int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st) {
+    DudfProfScope prof(PROF_SWEEP_FWD + (which & 3), st);
+    switch (H) {
+        case 256: return launch_b<256>(which, a, st);
+        default: return DUDF_E_UNSUPPORTED;
+    }
+}
+
+int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
+    if (lo.H != 256 || lo.L < 2) return 0;
+    DudfProfScope prof(PROF_PACK, st);
+    using G = GeoB<256>;
+    char* img_f = reinterpret_cast<char*>(ws + lo.ws_wimg);
+    char* img_t = img_f + (size_t)(lo.L - 1) * G::IMGB;
+    const int64_t total = (int64_t)2 * (lo.L - 1) * G::NKB * G::NT * 64;
+    hipLaunchKernelGGL(pack_bf16_kernel<256>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, theta, img_f, img_t,
+                       lo.L - 1, lo.off_hid, lo.hid_stride);
+    return (int)hipGetLastError();
+}
