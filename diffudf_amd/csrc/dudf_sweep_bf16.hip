@@ -25,8 +25,8 @@
 //     (k-block, 16-row tile, piece) the 1 KiB that one ds_read_b128 wave-instruction fetches, lane L = (g<<4 | m)
 //     holding M[row m][the 8 features of k-slots (g, 0..7)].  The 48 KiB of a k-block (16 tiles x 3 pieces at H = 256)
 //     are contiguous, so LDS-DMA moves them verbatim in 1 KiB wave-instructions and the reads are lane-linear:
-//     conflict-free without padding or swizzle.  Double buffered (96 KiB), one barrier per k-block, hand-counted
-//     vmcnt as in the f32 kernel.  128 columns share every byte fetched from L2: at bf16 rates the f32 kernel's
+//     conflict-free without padding or swizzle.  Three buffers (144 KiB), fetched two steps ahead, one barrier per
+//     k-block, hand-counted vmcnt as in the f32 kernel.  128 columns share every byte fetched from L2: at bf16 rates the f32 kernel's
 //     64-column workgroups would be bound by L2 -> LDS weight traffic, not by the matrix cores.
 //   * the first layer (K = 3+1) and the output / df/dx matmuls stay on the fp32 MFMA.
 #include "dudf_sweep_common.h"
@@ -161,8 +161,17 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile,
         else asm volatile("" : "+v"(o.o1a), "+v"(o.o2a), "+v"(o.o1b), "+v"(o.o2b));
     };
 
+    // chunk stream: chunk c = (matrix c / NKB, k-block c % NKB) lives in LDS buffer c % 3 and is fetched TWO steps
+    // ahead.  vmcnt retires in order, so a one-step-ahead DMA would force every stash load and store of the previous
+    // step to complete within one step as well; with two steps everything gets two (~3 us, an HBM round trip under load).
+    const int total = nhid * G::NKB;
+    auto chunk_src = [&](int c) -> const char* {       // c is wave-uniform
+        const int j = c / G::NKB;
+        return image(j) + (size_t)(c - j * G::NKB) * G::CHUNKB;
+    };
     __syncthreads();                                   // every wave is past its last LDS read of the previous tile
-    dma_issue<H>(image(0), lds + (gc & 1) * G::CHUNKB, lane, wave);
+    dma_issue<H>(chunk_src(0), lds + gc * G::CHUNKB, lane, wave);
+    dma_issue<H>(chunk_src(1), lds + ((gc + 1) % 3) * G::CHUNKB, lane, wave);
 
     // ------------------------------ first layer (fp32, K = 3): pre-activations / incoming adjoints of 16 tiles -------
     {
@@ -178,44 +187,41 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile,
     }
 
     // ------------------------------ hidden x hidden layers ------------------------------
-    // Step kb of matrix j:  [operands of tail kb+1 have landed] -> DMA of the next chunk -> operand loads of tail kb+2
-    // -> 16 tiles x 6 MFMAs with B(kb), interleaved with tail kb+1 -> B(kb+1) -> dma_wait + barrier.
-    // No compiler-visible vector-memory wait may sit between a DMA issue and its dma_wait (hipcc does not see the asm
-    // DMA in its vmcnt bookkeeping), hence the pins.
-    TailOps ops_next, ops_cur;                         // in flight for the tail after next / pinned for the next one
+    // Step c:  [operands of tail c+1 have landed] -> DMA of chunk c+2 -> operand loads of tail c+3 -> 16 tiles x 6
+    // MFMAs with B(c), interleaved with tail c+1 -> B(c+1) -> wait for chunk c+1 + barrier.  Tail t = pair t % NKB of
+    // the layer feeding matrix t / NKB; the last step of a layer runs the first tail of the next one once its own
+    // accumulators are final.
+    TailOps ops_cur, ops_n1, ops_n2;                   // pinned for the next tail / loaded one step ago / being loaded
     u32x4 bh, bm, bl;                                  // B operand of the current step
+    f32x4 fin0 = {0, 0, 0, 0}, fin1 = {0, 0, 0, 0};    // fp32 results of pair 0 of the layer after the last matrix
     load_ops(in_layer(0), 0, ops_cur);
-    load_ops(in_layer(0), 1, ops_next);
-    for (int j = 0; j < nhid; ++j) {
-        const char* M = image(j);
-        const char* Mn = (j + 1 < nhid) ? image(j + 1) : nullptr;
-        const int lin = in_layer(j), lnx = in_layer(j + 1);
-        {   // B(0): tail of the previous layer's tiles 0, 1 — nothing of this layer can start before it
-            f32x4 e0, e1;
-            pin_ops(ops_cur);
-            run_tail(lin, 0, prev[0], prev[1], ops_cur, e0, e1);
-            split8(e0, e1, bh, bm, bl);
-        }
+    load_ops(in_layer(0), 1, ops_n1);
+    load_ops(in_layer(0), 2, ops_n2);
+    {
+        f32x4 e0, e1;
+        run_tail(in_layer(0), 0, prev[0], prev[1], ops_cur, e0, e1);
+        split8(e0, e1, bh, bm, bl);
+    }
 #pragma unroll
-        for (int T = 0; T < G::NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
-        if (j == 0) dma_wait_b<0>();
-        else dma_wait_b<younger_b<SW, FL>()>();
-        __syncthreads();
+    for (int T = 0; T < G::NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
+    dma_wait_b<0>();                                   // once per tile: chunks 0 and 1 and everything above
+    __syncthreads();
+    constexpr int kYoung = younger_b<SW, FL>();
+    for (int j = 0; j < nhid; ++j) {
+        const int lin = in_layer(j), lnx = in_layer(j + 1);
 #pragma unroll
         for (int kb = 0; kb < G::NKB; ++kb) {
-            const char* bp = lds + (gc & 1) * G::CHUNKB + lane * 16;
+            const int c = j * G::NKB + kb;
+            const char* bp = lds + gc * G::CHUNKB + lane * 16;
             auto frag = [&](int T, int pc) -> bf16x8 {
                 return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
             };
-            // operands of tail kb+1 (loaded one step ago) -> ops_cur; the compiler's wait sits before the DMA issue
-            ops_cur = ops_next;
+            ops_cur = ops_n1; ops_n1 = ops_n2;
             pin_ops(ops_cur);
-            char* nbuf = lds + ((gc + 1) & 1) * G::CHUNKB;
-            if (kb + 1 < G::NKB) dma_issue<H>(M + (size_t)(kb + 1) * G::CHUNKB, nbuf, lane, wave);
-            else if (Mn) dma_issue<H>(Mn, nbuf, lane, wave);
-            // operand loads two tails ahead: (lin, kb+2), or the first two pairs of the next layer's input
-            if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_next);
-            else load_ops(lnx, kb + 2 - G::NKB, ops_next);
+            const bool more = c + 2 < total;
+            if (more) dma_issue<H>(chunk_src(c + 2), lds + ((gc + 2) % 3) * G::CHUNKB, lane, wave);
+            if (kb + 3 < G::NKB) load_ops(lin, kb + 3, ops_n2);
+            else load_ops(lnx, kb + 3 - G::NKB, ops_n2);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 nh, nm, nl;
             bf16x8 an[3] = {frag(0, 0), frag(0, 1), frag(0, 2)};
@@ -226,41 +232,47 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile,
                     an[0] = frag(T + 1, 0); an[1] = frag(T + 1, 1); an[2] = frag(T + 1, 2);
                     __builtin_amdgcn_sched_barrier(0x7F);
                 }
-                f32x4 c = acc[T];
-                c = mfma_b(am, as_bf(bm), c);                           // smallest terms first
-                c = mfma_b(al, as_bf(bh), c);
-                c = mfma_b(ah, as_bf(bl), c);
-                c = mfma_b(am, as_bf(bh), c);
-                c = mfma_b(ah, as_bf(bm), c);
-                c = mfma_b(ah, as_bf(bh), c);
-                acc[T] = c;
+                f32x4 cc = acc[T];
+                cc = mfma_b(am, as_bf(bm), cc);                         // smallest terms first
+                cc = mfma_b(al, as_bf(bh), cc);
+                cc = mfma_b(ah, as_bf(bl), cc);
+                cc = mfma_b(am, as_bf(bh), cc);
+                cc = mfma_b(ah, as_bf(bm), cc);
+                cc = mfma_b(ah, as_bf(bh), cc);
+                acc[T] = cc;
                 if (T == 0 && kb + 1 < G::NKB) {                        // the next step's B operand, between the MFMAs
                     f32x4 e0, e1;
                     run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
                     split8(e0, e1, nh, nm, nl);
                 }
             }
-            if (kb + 1 < G::NKB) { bh = nh; bm = nm; bl = nl; }
-            ++gc;
-            if (kb + 1 < G::NKB || Mn) {
-                if (kb + 1 < G::NKB) dma_wait_b<younger_b<SW, FL>()>();
-                // (the wait for the next layer's first chunk sits after B(0)'s tail, above)
-            }
-            if (kb + 1 < G::NKB) __syncthreads();
-        }
+            if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
+                run_tail(lnx, 0, acc[0], acc[1], ops_cur, fin0, fin1);
+                split8(fin0, fin1, nh, nm, nl);
 #pragma unroll
-        for (int T = 0; T < G::NT; ++T) prev[T] = acc[T];
+                for (int T = 0; T < G::NT; ++T) { prev[T] = acc[T]; acc[T] = f32x4{0, 0, 0, 0}; }
+            }
+            bh = nh; bm = nm; bl = nl;
+            gc = (gc + 1) % 3;
+            if (more) dma_wait_b<2 * kYoung + G::NDMA>();               // chunk c+1 landed; c+2 and two steps' stash traffic stay in flight
+            else dma_wait_b<0>();
+            __syncthreads();
+        }
     }
 
-    // ------------------------------ tails of the last hidden layer + output stage (fp32) ------------------------------
+    // ------------------------------ remaining tails of the last hidden layer + output stage (fp32) -------------------
     {
         const int lin = in_layer(nhid);
         float part = 0.f;
         f32x4 accg = {0, 0, 0, 0};
 #pragma unroll
         for (int kb = 0; kb < G::NKB; ++kb) {
-            f32x4 e0, e1;
-            run_tail(lin, kb, prev[2 * kb], prev[2 * kb + 1], ops_cur, e0, e1);
+            f32x4 e0 = fin0, e1 = fin1;
+            if (kb > 0) {
+                ops_cur = ops_n1; ops_n1 = ops_n2;
+                run_tail(lin, kb, prev[2 * kb], prev[2 * kb + 1], ops_cur, e0, e1);
+                if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_n2);
+            }
             if constexpr (BS == SWEEP_FWD) {
                 const f32x4 w0v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 4 * q);
                 const f32x4 w1v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 16 + 4 * q);
@@ -274,8 +286,6 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile,
 #pragma unroll
                 for (int t = 0; t < 4; ++t) accg = mfma16(w1v[t], e1[t], accg);
             }
-            ops_cur = ops_next;
-            if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_next);
         }
         if constexpr (BS == SWEEP_FWD) {
             part += __shfl_xor(part, 16);
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
 template <int H>
 int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoB<H>;
-    const size_t smem = 2 * G::CHUNKB;
+    const size_t smem = 3 * G::CHUNKB;
     if (a.ntiles <= 0) return 0;
     const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;
     int grid = ntb < 256 ? ntb : 256;                  // one resident 8-wave workgroup per CU

@@ -20,6 +20,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // and no per-tile 64-bit address is kept in VGPRs.
 #define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>((arr) + (ub) + (vo))
 #define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>((arr) + (ub) + (vo))
+// the stash is a stream (written once, read once or twice, 14 GB per step): non-temporal accesses
+#define DUDF_ST(arr, ub, vo, val) __builtin_nontemporal_store((f32x4)(val), DUDF_AT(arr, ub, vo))
+#define DUDF_LD(arr, ub, vo) __builtin_nontemporal_load(DUDF_CAT(arr, ub, vo))
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
 __device__ __forceinline__ float quad_bcast0(float v) {          // value of the quad's lane 0 (the value channel)
@@ -93,22 +96,22 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             dudf_sincos(a.w0 * acc[t], &sv, &cv);
             s[t] = sv; c[t] = cv;
         }
-        if constexpr (FL & 1) *DUDF_AT(a.S, ub, vo) = s;
-        if constexpr (FL & 2) *DUDF_AT(a.C, ub, vo) = c;
+        if constexpr (FL & 1) DUDF_ST(a.S, ub, vo, s);
+        if constexpr (FL & 2) DUDF_ST(a.C, ub, vo, c);
         out = s;
     } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
         out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
         if constexpr (FL & 1) {
-            *DUDF_AT(a.Q, ub, vo) = out;
-            *DUDF_AT(a.R, ub, vo) = (a.w0 * a.w0) * o2 * acc;   // r_l = w0^2 s_l a_l
+            DUDF_ST(a.Q, ub, vo, out);
+            DUDF_ST(a.R, ub, vo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
-        *DUDF_AT(a.A, ub, vo) = out;
-        *DUDF_AT(a.E, ub, vo) = o2 * acc;            // e_l = r_l Q_l
+        DUDF_ST(a.A, ub, vo, out);
+        DUDF_ST(a.E, ub, vo, o2 * acc);            // e_l = r_l Q_l
     } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
-        *DUDF_AT(a.Z, ub, vo) = out;
+        DUDF_ST(a.Z, ub, vo, out);
     } else if constexpr (SW == SWEEP_FWD_H) {
         f32x4 c, zs;
 #pragma unroll
@@ -119,9 +122,9 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             zs[t] = isv ? sv : acc[t];
             out[t] = isv ? sv : a.w0 * cv * acc[t];
         }
-        *DUDF_AT(a.C, ub, vo) = c;
-        *DUDF_AT(a.ZS, ub, vo) = zs;
-        if constexpr (FL & 1) *DUDF_AT(a.S, ub, vo) = out;
+        DUDF_ST(a.C, ub, vo, c);
+        DUDF_ST(a.ZS, ub, vo, zs);
+        if constexpr (FL & 1) DUDF_ST(a.S, ub, vo, out);
     } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -129,8 +132,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = isv ? a.w0 * o1[t] * acc[t] : a.w0 * (o1[t] * acc[t] - a.w0 * sv * o2[t] * a0);
         }
         if constexpr (FL & 1) {
-            *DUDF_AT(a.Q, ub, vo) = out;
-            *DUDF_AT(a.R, ub, vo) = acc;
+            DUDF_ST(a.Q, ub, vo, out);
+            DUDF_ST(a.R, ub, vo, acc);
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {    // o1 = c, o2 = s|zdot^k, o3 = a|adot^k
         f32x4 e;
@@ -147,8 +150,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = a.w0 * (o1[t] * acc[t] + (isv ? s1 : 0.f));
             e[t] = isv ? a.w0 * (o1[t] * sbar - sv * cbar) : -a.w0 * sv * chat;
         }
-        *DUDF_AT(a.A, ub, vo) = out;
-        *DUDF_AT(a.E, ub, vo) = e;
+        DUDF_ST(a.A, ub, vo, out);
+        DUDF_ST(a.E, ub, vo, e);
     } else if constexpr (SW == SWEEP_FWD_J) {
         const int lane = threadIdx.x & 63, l0 = lane & 48;
         const unsigned jw = kJetLane[lane & 15];
@@ -174,7 +177,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             const float st = quad_sum(isv ? 0.f : o2[t] * acc[t]);
             out[t] = o3[t] + a.w0 * o1[t] * acc[t] - (isv ? a.w0 * a.w0 * sv * st : 0.f);
         }
-        *DUDF_AT(a.Z, ub, vo) = out;
+        DUDF_ST(a.Z, ub, vo, out);
     }
     return out;
 }
@@ -184,25 +187,25 @@ __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, u
                                                f32x4& o3) {
     o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
     if constexpr (SW == SWEEP_REV) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = *DUDF_CAT(a.S, ub, vo);
+        o1 = DUDF_LD(a.C, ub, vo);
+        if constexpr (FL & 1) o2 = DUDF_LD(a.S, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.R, ub, vo);
+        o1 = DUDF_LD(a.C, ub, vo);
+        o2 = DUDF_LD(a.R, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = *DUDF_CAT(a.E, ub, vo);            // no df/dx terms (loss_s2): e_l == 0
+        o1 = DUDF_LD(a.C, ub, vo);
+        if constexpr (FL & 1) o2 = DUDF_LD(a.E, ub, vo);            // no df/dx terms (loss_s2): e_l == 0
     } else if constexpr (SW == SWEEP_REV_H) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.ZS, ub, vo);
+        o1 = DUDF_LD(a.C, ub, vo);
+        o2 = DUDF_LD(a.ZS, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.ZS, ub, vo);
-        o3 = *DUDF_CAT(a.R, ub, vo);
+        o1 = DUDF_LD(a.C, ub, vo);
+        o2 = DUDF_LD(a.ZS, ub, vo);
+        o3 = DUDF_LD(a.R, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_REV_H) {
-        o1 = *DUDF_CAT(a.C, ub, vo);
-        o2 = *DUDF_CAT(a.ZS, ub, vo);
-        o3 = *DUDF_CAT(a.E, ub, vo);
+        o1 = DUDF_LD(a.C, ub, vo);
+        o2 = DUDF_LD(a.ZS, ub, vo);
+        o3 = DUDF_LD(a.E, ub, vo);
     }
 }
 

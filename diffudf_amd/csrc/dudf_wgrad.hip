@@ -301,9 +301,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
                 const unsigned dst = __builtin_amdgcn_readfirstlane(
                     (unsigned)(size_t)(__attribute__((address_space(3))) float*)(ring + oper * OPER + piece * 256));
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\t"
                              "s_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");    // nt: the stash is read once here
             }
         }
     };

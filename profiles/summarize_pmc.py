@@ -23,9 +23,12 @@ NAMES = {"<256, 0, 3>": "sweep_fwd", "<256, 1, 1>": "sweep_rev", "<256, 2, 0>": 
 
 
 def kname(k):
+    if "sweep_bf16_kernel" in k:
+        sig = k.split("sweep_bf16_kernel")[1].split("(")[0]
+        return NAMES.get(sig, "sweep" + sig)
     if "sweep_kernel" in k:
         sig = k.split("sweep_kernel")[1].split("(")[0]
-        return NAMES.get(sig, "sweep" + sig)
+        return NAMES.get(sig, "sweep" + sig) + "_f32"
     for n in ("wgrad_hidden_bf16", "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel", "pack_kernel"):
         if n in k:
             return n.replace("_kernel", "").replace("wgrad_hidden_bf16", "wgrad_hidden")
