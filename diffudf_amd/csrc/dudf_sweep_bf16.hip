@@ -111,8 +111,10 @@ constexpr int younger_b() {
 
 struct TailOps { f32x4 o1a, o2a, o1b, o2b, ba, bb; };   // operands of one pair of tiles (+ bias, forward sweep)
 
+// One pass: the workgroup's waves 0..nact-1 take the 16-column groups g_first.. through a whole sweep.  Waves beyond
+// nact (the last, partial pass of a workgroup's share) only keep the weight stream and the barriers going.
 template <int H, int SW, int FL>
-__device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile, char* lds, unsigned& gc) {
+__device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
     using G = GeoB<H>;
     static_assert(!is_hess(SW), "plain columns only");
     constexpr int BS = base_of(SW);
@@ -123,7 +125,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile,
     constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
 
     f32x4 acc[G::NT], prev[G::NT];                     // this layer's accumulators / the previous layer's, tails pending
-    const int64_t p = (int64_t)tile * TILEB + wave * 16 + li;
+    const int64_t p = (int64_t)(g_first + wave) * 16 + li;
     auto image = [&](int j) -> const char* {
         return kFwdDir ? a.wimg_f + (size_t)j * G::IMGB : a.wimg_t + (size_t)(nhid - 1 - j) * G::IMGB;
     };
@@ -172,6 +174,19 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int tile,
     __syncthreads();                                   // every wave is past its last LDS read of the previous tile
     dma_issue<H>(chunk_src(0), lds + gc * G::CHUNKB, lane, wave);
     dma_issue<H>(chunk_src(1), lds + ((gc + 1) % 3) * G::CHUNKB, lane, wave);
+    if (wave >= nact) {                                // same DMA pieces, same barriers, nothing else
+        dma_wait_b<0>();
+        __syncthreads();
+        for (int c = 0; c < total; ++c) {
+            const bool more = c + 2 < total;
+            if (more) dma_issue<H>(chunk_src(c + 2), lds + ((gc + 2) % 3) * G::CHUNKB, lane, wave);
+            gc = (gc + 1) % 3;
+            if (more) dma_wait_b<G::NDMA>();           // only this step's pieces may still be in flight
+            else dma_wait_b<0>();
+            __syncthreads();
+        }
+        return;
+    }
 
     // ------------------------------ first layer (fp32, K = 3): pre-activations / incoming adjoints of 16 tiles -------
     {
@@ -302,9 +317,12 @@ template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
-    const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;           // this kernel's tiles are 128 columns wide
-    for (int t = blockIdx.x; t < ntb; t += gridDim.x)
-        sweep_tile_b<H, SW, FL>(a, a.tile0 * TILE / TILEB + t, lds_b, gc);
+    // balanced shares of 16-column groups; a share is walked in passes of 8 groups, the last one possibly partial —
+    // a pass with one wave per SIMD (or a single wave) costs about half a full one, a whole extra round would cost all of it
+    const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
+    const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
+    for (int g = g0; g < g1; g += NWB)
+        sweep_tile_b<H, SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc);
 }
 
 // theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L

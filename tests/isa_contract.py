@@ -51,3 +51,39 @@ def analyse(asm_path):
 if __name__ == "__main__":
     for k, v in sorted(analyse(sys.argv[1]).items(), key=str):
         print(k, v["scratch"], v["pairs"], "drains:", v["drains"])
+
+
+def analyse_bf16(asm_path, ndma=6):
+    """bf16x6 sweep kernels (dudf_sweep_bf16.hip): weight chunks are fetched TWO steps ahead, so the hand-written wait
+    at the end of a step must leave in flight this step's DMA pieces plus two steps' compiler-issued stash traffic:
+    N == 2 * (vector-memory instructions hipcc placed in the step) + ndma.  Returns per kernel
+    {"steps": [(dma pieces, compiler ops, N)], "idle": [N of the idle-wave loop], "scratch": count}."""
+    txt = open(asm_path).read()
+    out = {}
+    for m in re.finditer(r"^(_ZN\w*sweep_bf16_kernelILi256ELi(\d)ELi(\d)E\w*):[^\n]*$", txt, re.M):
+        end = txt.index("s_endpgm", m.end())
+        body = txt[m.end():end]
+        in_asm, dma, other, scratch, steps, idle = False, 0, 0, 0, [], []
+        for ln in body.split("\n"):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            if t.startswith("scratch_"):
+                scratch += 1
+            if t.startswith("global_load_lds"):
+                dma += 1
+            elif re.match(r"(global_load|global_store|global_atomic|buffer_|flat_)", t):
+                other += 1
+            elif t.startswith("s_waitcnt") and "vmcnt" in t and in_asm:
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                if n == 0:
+                    continue                     # drains (tile start, last two steps): always safe
+                if n == ndma and other == 0:
+                    idle.append(n)
+                else:
+                    steps.append((dma, other, n))
+                dma = other = 0
+        out[(int(m.group(2)), int(m.group(3)))] = {"steps": steps, "idle": idle, "scratch": scratch}
+    return out

@@ -8,7 +8,7 @@ import pytest
 
 import sys, os as _os
 sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-from isa_contract import analyse, emit_asm
+from isa_contract import analyse, analyse_bf16, emit_asm
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,3 +26,25 @@ def test_dma_wait_counts(tmp_path):
     # the training variants must not spill
     for key in ((0, 3), (1, 1), (2, 0), (3, 1), (3, 0)):
         assert res[key]["scratch"] == 0, key
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_bf16_sweep_wait_counts(tmp_path):
+    """dudf_sweep_bf16.hip: every step's counted wait leaves exactly this step's DMA pieces and two steps of stash
+    traffic in flight (a larger N would let a wave read a weight chunk that has not landed; a smaller one only
+    stalls), the idle-wave loop waits for all but its newest pieces, and nothing spills at 2 waves per SIMD."""
+    asm = str(tmp_path / "sweep_bf16.s")
+    emit_asm(os.path.join(REPO, "diffudf_amd", "csrc", "dudf_sweep_bf16.hip"), asm)
+    res = analyse_bf16(asm)
+    assert set(res) == {(0, 3), (1, 1), (1, 0), (2, 0), (3, 1), (3, 0)}
+    for key, v in res.items():
+        assert v["scratch"] == 0, key
+        for dma, ops, n in v["steps"]:
+            assert n <= 2 * ops + dma, f"sweep_bf16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) with {ops} ops/step"
+        # the unrolled steps of a layer (the first entry also carries the first layer's prologue traffic)
+        kmin = min(s[1] for s in v["steps"] if s[0] == 6)
+        steady = [s for s in v["steps"] if s[0] == 6 and s[1] == kmin]
+        assert len(steady) >= 7, (key, v["steps"])
+        for dma, ops, n in steady:
+            assert n == 2 * ops + dma, (key, dma, ops, n)          # and not needlessly small either
+        assert any(s == (6, 0, 6) or s[2] == 6 for s in v["steps"]) or v["idle"], key     # the idle-wave loop's vmcnt(NDMA)
