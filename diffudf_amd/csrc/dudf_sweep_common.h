@@ -15,6 +15,32 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// dudf_sincos (dudf_math.h) on two values at once: the same operations in the same order — so the same bits — but the
+// FMA/MUL chains are written on float2 so that hipcc emits the packed v_pk_fma_f32 / v_pk_mul_f32 (two lanes-worth of
+// work per issue slot).  The forward sweep is bound by vector-ALU issue once its matmuls run on the bf16 cores.
+typedef float dudf_f2 __attribute__((ext_vector_type(2)));
+typedef int dudf_i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2& c_out) {
+    const dudf_f2 k = {rintf(x.x * 0.636619772367581343f), rintf(x.y * 0.636619772367581343f)};
+    dudf_f2 r = __builtin_elementwise_fma(-k, (dudf_f2)(1.57079637050628662109375f), x);
+    r = __builtin_elementwise_fma(-k, (dudf_f2)(-4.37113900018624283e-8f), r);
+    const dudf_i2 n = {(int)k.x, (int)k.y};
+    const dudf_f2 r2 = r * r;
+    dudf_f2 ps = __builtin_elementwise_fma(r2, (dudf_f2)(-1.9515295891e-4f), (dudf_f2)(8.3321608736e-3f));
+    ps = __builtin_elementwise_fma(r2, ps, (dudf_f2)(-1.6666654611e-1f));
+    const dudf_f2 sr = __builtin_elementwise_fma(r * r2, ps, r);
+    dudf_f2 pc = __builtin_elementwise_fma(r2, (dudf_f2)(2.443315711809948e-5f), (dudf_f2)(-1.388731625493765e-3f));
+    pc = __builtin_elementwise_fma(r2, pc, (dudf_f2)(4.166664568298827e-2f));
+    const dudf_f2 cr = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (dudf_f2)(-0.5f), (dudf_f2)(1.0f)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float sa = (n[i] & 1) ? cr[i] : sr[i];
+        const float ca = (n[i] & 1) ? sr[i] : cr[i];
+        s_out[i] = (n[i] & 2) ? -sa : sa;
+        c_out[i] = ((n[i] + 1) & 2) ? -ca : ca;
+    }
+}
+
 // Stash addressing: `ub` is a WAVE-UNIFORM float offset (layer and tile folded in, lives in SGPRs),
 // `vo` the lane's 32-bit float offset ((quarter*np + point)*4): global_load/store take the saddr form
 // and no per-tile 64-bit address is kept in VGPRs.
@@ -91,10 +117,10 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
     if constexpr (SW == SWEEP_FWD) {
         f32x4 s, c;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float sv, cv;
-            dudf_sincos(a.w0 * acc[t], &sv, &cv);
-            s[t] = sv; c[t] = cv;
+        for (int t = 0; t < 4; t += 2) {
+            dudf_f2 sv, cv;
+            dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
+            s[t] = sv.x; s[t + 1] = sv.y; c[t] = cv.x; c[t + 1] = cv.y;
         }
         if constexpr (FL & 1) DUDF_ST(a.S, ub, vo, s);
         if constexpr (FL & 2) DUDF_ST(a.C, ub, vo, c);

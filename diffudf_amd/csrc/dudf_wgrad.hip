@@ -413,16 +413,18 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
         float w1[4][4], wo[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = w1[c][3] = 0.f; }
+#pragma unroll 4
         for (int64_t p = p0 + lane; p < p1; p += 64) {
             const int64_t off = ((int64_t)fq * a.np + p) * 4;
-            const f32x4 z = *reinterpret_cast<const f32x4*>(Z0 + off);
-            const f32x4 sl = *reinterpret_cast<const f32x4*>(SL + off);
+            // the stash is a stream (last reader of these rows); x4 / gbar / ybar are re-read per feature quad: cached
+            const f32x4 z = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Z0 + off));
+            const f32x4 sl = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(SL + off));
             const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x4 + p * 4);
             const float yb = a.ybar[p];
             f32x4 qv = {0, 0, 0, 0}, al = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
             if (a.have_g) {
-                qv = *reinterpret_cast<const f32x4*>(Q0 + off);
-                al = *reinterpret_cast<const f32x4*>(AL + off);
+                qv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Q0 + off));
+                al = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(AL + off));
                 gb = *reinterpret_cast<const f32x4*>(a.gbar + p * 4);
             }
 #pragma unroll
@@ -513,7 +515,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
-    s.pts_per_block = 512;
+    s.pts_per_block = 1024;
     const int grid = (int)((lo.np + s.pts_per_block - 1) / s.pts_per_block);
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
     const int gy = (lo.H / 4 >= 16) ? 4 : 1;
