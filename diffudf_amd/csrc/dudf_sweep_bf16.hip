@@ -239,12 +239,14 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             else load_ops(lnx, kb + 3 - G::NKB, ops_n2);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 nh, nm, nl;
-            bf16x8 an[3] = {frag(0, 0), frag(0, 1), frag(0, 2)};
+            // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
+            // chunk DMA on the LDS, one tile of distance does not cover the read latency
+            bf16x8 an[2][3] = {{frag(0, 0), frag(0, 1), frag(0, 2)}, {frag(1, 0), frag(1, 1), frag(1, 2)}};
 #pragma unroll
             for (int T = 0; T < G::NT; ++T) {
-                const bf16x8 ah = an[0], am = an[1], al = an[2];
-                if (T + 1 < G::NT) {
-                    an[0] = frag(T + 1, 0); an[1] = frag(T + 1, 1); an[2] = frag(T + 1, 2);
+                const bf16x8 ah = an[T & 1][0], am = an[T & 1][1], al = an[T & 1][2];
+                if (T + 2 < G::NT) {
+                    an[T & 1][0] = frag(T + 2, 0); an[T & 1][1] = frag(T + 2, 1); an[T & 1][2] = frag(T + 2, 2);
                     __builtin_amdgcn_sched_barrier(0x7F);
                 }
                 f32x4 cc = acc[T];
