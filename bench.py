@@ -30,6 +30,7 @@ import torch  # noqa: E402
 W_EIKONAL = [1e4, 1e4, 0.0, 1e3]       # loss_s1 weights with the Hessian term off = the headline metric
 ALPHA = 100.0
 PEAK_F32_MFMA_TFLOPS = 157.3           # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_TB_S = 8.0                     # HBM3E, same table
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table: BF16 MFMA, dense
 
 
@@ -188,6 +189,9 @@ def main():
         # which matrix-core instruction a kernel runs on: f32-input MFMA (1 MFMA flop per algorithmic flop, 157.3 TF)
         # or the 3-way bf16 split at fp32 accuracy (6 bf16 MFMA flops per algorithmic flop, 2.5 PF dense)
         bf16x6 = {"wgrad_hidden"} if os.environ.get("DUDF_WGRAD", "bf16")[0] != "f" else set()
+        if (args.hidden == 256 and args.layers >= 2 and n_hess == 0
+                and os.environ.get("DUDF_SWEEP", "bf16")[0] != "f"):      # csrc/dudf_sweep_bf16.hip: plain columns, H = 256
+            bf16x6 |= {"sweep_fwd", "sweep_rev", "sweep_adj_fwd", "sweep_adj_rev"}
         # columns the MFMA kernels actually process: 1 per plain point, 4 per Hessian-path point
         n_local = args.points + 3 * n_hess
         per_kernel = {}
@@ -202,11 +206,27 @@ def main():
         dom = max((k for k in per_kernel), key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
         mfma_ms = sum(kern[k]["avg_ms"] for k in alg if k in kern)
         step_tf = 6 * F0 * n_local / (mfma_ms * 1e-3) / 1e12 if mfma_ms else None
-        traffic = None
+        traffic, step_hbm = None, None
         prof_json = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if dom and os.path.exists(prof_json):
-            try:
-                traffic = json.load(open(prof_json)).get(dom, {}).get("hbm_bytes_per_launch")
+        if dom and os.path.exists(prof_json) and args.points == 100000 and args.loss == "eikonal" and args.hidden == 256:
+            try:                                        # PMC bytes were collected on exactly this workload
+                tr = json.load(open(prof_json))
+                traffic = tr.get(dom, {}).get("hbm_bytes_per_launch")
+                tot = 0.0
+                for k, d in per_kernel.items():
+                    b = tr.get(k, {}).get("hbm_bytes_per_launch")
+                    if b:
+                        d["hbm_bytes_per_launch"] = b
+                        d["hbm_tb_s"] = round(b / (d["avg_ms"] * 1e-3) / 1e12, 2)
+                        d["hbm_frac_of_8tb_s"] = round(d["hbm_tb_s"] / PEAK_HBM_TB_S, 3)
+                        tot += b
+                if tot:
+                    step_hbm = {"bytes_per_step": tot, "bytes_per_point": round(tot / args.points),
+                                "tb_s_over_mfma_kernels": round(tot / (mfma_ms * 1e-3) / 1e12, 2),
+                                "frac_of_8tb_s": round(tot / (mfma_ms * 1e-3) / 1e12 / PEAK_HBM_TB_S, 3),
+                                "note": "stash traffic between the sweeps and the weight-gradient GEMM; with the "
+                                        "matmuls on the bf16 cores this, not the matrix pipe, is what the step "
+                                        "approaches first (plain streaming kernels reach 5.1-5.7 TB/s on this part)"}
             except Exception:
                 traffic = None
         roofline = None
@@ -223,6 +243,7 @@ def main():
                         "all_mfma_kernels": per_kernel,
                         "step_algorithmic_tflops": round(step_tf, 2) if step_tf else None,
                         "step_frac_of_f32_matrix_peak": round(step_tf / PEAK_F32_MFMA_TFLOPS, 4) if step_tf else None,
+                        "step_hbm": step_hbm,
                         "other_kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items() if k not in alg}}
         out = {
             "metric": "train points/sec (SIREN fwd+∇x+Eikonal loss+bwd), 256×8 net, 100k pts" if args.loss == "eikonal"
@@ -230,9 +251,11 @@ def main():
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "exact fp32 arithmetic: f32-input MFMA in the sweeps; the weight-gradient GEMM runs on bf16 MFMA "
-                          "with both fp32 operands split exactly into three bf16 pieces (6 products, fp32 accumulate), "
-                          "held to the same parity tolerances as the f32 kernel (DUDF_WGRAD=f32 selects that one)",
+            "dtype_note": "fp32 arithmetic throughout. The hidden-layer matmuls of the sweeps (H = 256 plain columns) and the "
+                          "weight-gradient GEMM run on bf16 MFMA with BOTH fp32 operands split exactly into three bf16 "
+                          "pieces (6 products, fp32 accumulate: fp32-equivalent, held to the same parity tolerances as "
+                          "the f32-input MFMA kernels, which DUDF_SWEEP=f32 / DUDF_WGRAD=f32 select); first/last layer, "
+                          "tails, loss and Adam are plain fp32",
             "config": {"workload": f"SIREN {args.layers}x{args.hidden} (w0=30), loss_s1 weights {weights} "
                                    f"({'Eikonal-only' if args.loss == 'eikonal' else 'Hessian term on'}), alpha=100, {args.points} synthetic points per GPU "
                                    f"(global batch {n_global}), step = fwd + df/dx + loss + bwd + "

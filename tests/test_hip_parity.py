@@ -208,3 +208,46 @@ def test_unsupported_configs_fail_loudly(hip):
     cfg5 = hip.make_cfg([512] * 2)                  # Hessian path is not built for H = 512
     with pytest.raises(_lib.DudfError):
         hip.query_hessian(cfg5, torch.zeros(hip.theta_count(cfg5), device="cuda"), z)
+
+
+def test_f32_and_bf16x6_sweeps_agree():
+    """The 256-wide plain path runs its hidden matmuls on the bf16 cores (exact 3-way split, csrc/dudf_sweep_bf16.hip);
+    DUDF_SWEEP=f32 / DUDF_WGRAD=f32 select the f32-input MFMA kernels.  Both must meet the SAME oracle tolerances, and
+    agree with each other far inside them (the env is read once per process, hence the child process)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from diffudf_amd import hip_ops as hip, synth
+hid = [256] * 8
+th = torch.from_numpy(synth.flatten_params(synth.siren_params(hid, seed=123))).cuda()
+x, nrm, sdf = [torch.from_numpy(a).cuda() for a in synth.training_batch(1000, seed=5, step=0)]
+cfg = hip.make_cfg(hid)
+ws = hip.workspace_for(cfg, 1000, th.device)
+w = [1e4, 1e4, 0.0, 1e3]
+terms = hip.loss_forward(cfg, 0, th, x, nrm, sdf, 1000, w, 100.0, ws)
+g = hip.loss_backward(cfg, 0, th, x, nrm, sdf, 1000, w, 100.0, torch.ones(4, device="cuda"), None, ws)
+f, gr = hip.query(cfg, th, x)
+np.savez(sys.argv[1], terms=terms.cpu().numpy(), g=g.cpu().numpy(), f=f.cpu().numpy(), gr=gr.cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("bf16", {}), ("f32", {"DUDF_SWEEP": "f32", "DUDF_WGRAD": "f32"})):
+            path = os.path.join(td, tag + ".npz")
+            e = dict(os.environ); e.update(env)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=600)
+            outs[tag] = dict(np.load(path))
+    P = synth.siren_params([256] * 8, seed=123, dtype=np.float64)
+    x, nrm, sdf = synth.training_batch(1000, seed=5, step=0)
+    terms, grads, dbg = O.loss_and_grad("s1", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64),
+                                        [1e4, 1e4, 0.0, 1e3], 100.0)
+    gref = np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
+    for tag in ("bf16", "f32"):
+        assert rel(outs[tag]["f"], dbg["y"]) < 5e-6, tag
+        assert rel(outs[tag]["gr"], dbg["g"]) < 2e-5, tag
+        assert rel(outs[tag]["g"], gref) < 1e-4, tag
+        assert rel(outs[tag]["terms"], np.array(list(terms.values()))) < 1e-5, tag
+    assert rel(outs["bf16"]["f"], outs["f32"]["f"]) < 2e-6
+    assert rel(outs["bf16"]["g"], outs["f32"]["g"]) < 5e-6
