@@ -35,7 +35,7 @@ def main():
     model.to("cuda:0")
     F0 = 2 * (3 * 256 + 7 * 256 * 256 + 256)
     N = args.grid
-    extract_fields(model, None, 64, "tanh", "cuda:0", 100)
+    extract_fields(model, None, N, "tanh", "cuda:0", 100)              # warm: allocator, workspaces, code objects
     torch.cuda.synchronize(); t0 = time.perf_counter()
     df, vecs = extract_fields(model, None, N, "tanh", "cuda:0", 100)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -45,13 +45,21 @@ def main():
     M = args.rays ** 2
     x = torch.from_numpy(synth.training_batch(M, seed=5)[0]).cuda()
     cfg = model.hip_cfg
-    hip_ops.query_frame(cfg, model.flat_parameters(), x[:4096])
+    hip_ops.query_frame(cfg, model.flat_parameters(), x)               # warm (the 25 GB workspace is allocated here)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = hip_ops.query_frame(cfg, model.flat_parameters(), x)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(json.dumps({"metric": "Hessian frame query points/sec (value + df/dx + Hessian + eigh)", "value": M / dt,
                       "unit": "points/s", "points": M, "seconds": dt, "tflops_fp32_mfma": 8 * F0 * M / dt / 1e12,
                       "config": "BASELINE configs[3]: analytic d2f/dx2 kernel on 512^2 ray points"}))
+    hip_ops.query_curvature(cfg, model.flat_parameters(), x, want_shape=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = hip_ops.query_curvature(cfg, model.flat_parameters(), x, want_shape=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "curvature query points/sec (Hessian frame + third-order jet: shape operator, mean, gaussian)",
+                      "value": M / dt, "unit": "points/s", "points": M, "seconds": dt,
+                      "tflops_fp32_mfma": 24 * F0 * M / dt / 1e12,
+                      "config": "BASELINE configs[3]: src/render_st.py compute_normals_and_cd + compute_curvature on 512^2 ray points"}))
 
 
 if __name__ == "__main__":

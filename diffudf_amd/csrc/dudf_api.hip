@@ -71,8 +71,12 @@ int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
     }
     if (lo.ncol_n > 0) {
         a.tile0 = (int)(lo.ncol_h / DUDF_TILE_PTS); a.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); a.hess = 0;
-        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base, lo.H, lo.L)) rc = dudf_launch_sweep_bf16(base, lo.H, a, st);
-        else rc = dudf_launch_sweep(base, lo.H, a, st);
+        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base, lo.H, lo.L)) {
+            rc = dudf_launch_sweep_bf16(base, lo.H, a, st);
+        } else {
+            if (base == SWEEP_FWD) a.store_s = a.store_c = 1;     // the f32 kernel only builds its stash-everything variant
+            rc = dudf_launch_sweep(base, lo.H, a, st);
+        }
         if (rc) return rc;
     }
     return 0;
@@ -103,7 +107,10 @@ int forward_common(Ctx& c, const float* theta, const float* x, int train, bool r
     if (use_bf16_sweeps() && c.lo.ncol_n > 0 && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
     if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
-    a.store_s = 1; a.store_c = 1; a.train = train;
+    // what the forward sweep has to leave behind: h_l only for training (weight gradients, r_l), cos if any later sweep
+    // runs — a value-only query stores nothing, a value+gradient query half of what training does
+    a.store_s = train ? 1 : 0; a.store_c = (reverse || train) ? 1 : 0; a.train = train;
+    if (c.lo.ncol_h > 0) a.store_s = 1;                       // the Hessian quads' forward tail always keeps its outputs
     if ((rc = run_sweep(SWEEP_FWD, c.lo, a, c.st))) return rc;
     if (reverse && (rc = run_sweep(SWEEP_REV, c.lo, a, c.st))) return rc;
     return 0;

@@ -381,8 +381,10 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     } while (0)
     switch (which) {
         case SWEEP_FWD:
-            if (!(a.store_s && a.store_c)) return DUDF_E_BADMODE;
-            DUDF_GO_B(SWEEP_FWD, 3);
+            if (a.store_s && a.store_c) DUDF_GO_B(SWEEP_FWD, 3);
+            else if (a.store_c) DUDF_GO_B(SWEEP_FWD, 2);          // value + df/dx query: only cos is read again
+            else if (!a.store_s) DUDF_GO_B(SWEEP_FWD, 0);         // value-only query
+            else return DUDF_E_BADMODE;
             break;
         case SWEEP_REV:
             if (a.train) DUDF_GO_B(SWEEP_REV, 1); else DUDF_GO_B(SWEEP_REV, 0);

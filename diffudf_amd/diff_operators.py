@@ -57,7 +57,22 @@ def laplace(y, x):
 
 
 def jacobian(y, x):
-    raise DudfError("jacobian of a derived vector field: third-order path (SURVEY.md §7), not built yet")
+    """(jac (1,N,C,3), status) like reference src/diff_operators.py:214-227, for the two fields this path produces:
+    the model output (C = 1: the gradient) and the eigen-normal field returned by `render_st.compute_normals_and_cd`
+    (C = 3: the shape operator d n_i / d x_k, third derivatives of f, from `dudf_query_curvature`).  status = -1 if
+    the result holds a NaN, as in the reference."""
+    import torch
+    model, coords = _source(y, x)
+    x2 = coords.detach().reshape(-1, 3)
+    if y.shape[-1] == 1:
+        _, g = hip_ops.query(model.hip_cfg, model.flat_parameters(), x2, want_grad=True)
+        jac = g.reshape(1, -1, 1, 3)
+    elif getattr(y, "_dudf_kind", None) == "eig_normal":
+        _, _, _, _, shape = hip_ops.query_curvature(model.hip_cfg, model.flat_parameters(), x2, want_shape=True)
+        jac = shape.reshape(1, -1, 3, 3)
+    else:
+        raise DudfError("jacobian: only the model output and compute_normals_and_cd's normals have a HIP path")
+    return jac, (-1 if bool(torch.isnan(jac).any()) else 0)
 
 
 class _Fields(torch.autograd.Function):

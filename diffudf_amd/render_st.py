@@ -23,6 +23,7 @@ def compute_normals_and_cd(inputs, outputs):
     lead = coords.shape[:-1]
     normals = V[:, :, 2].reshape(lead + (3,))
     normals._dudf_src = (weakref.ref(model), coords)          # compute_curvature(inputs, normals) finds its way back
+    normals._dudf_kind = "eig_normal"
     return normals, V[:, :, :2].reshape(lead + (3, 2)).detach().cpu()
 
 

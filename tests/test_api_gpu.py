@@ -258,11 +258,17 @@ def test_curvature_against_reference(golden_dir, tag):
     mean = compute_curvature(xin, normals, curvature='mean')
     gauss = compute_curvature(xin, normals, curvature='gaussian')
     assert compute_curvature(xin, normals, curvature='none') is None
+    from src.diff_operators import jacobian                     # reference src/render_st.py:43 calls it directly
+    jac, status = jacobian(normals, xin)
+    assert status == 0 and jac.shape == (1, len(x), 3, 3)
+    jg, st2 = jacobian(y, xin)
+    assert st2 == 0 and jg.shape == (1, len(x), 1, 3)
     assert mean.shape == (1, len(x), 1) and gauss.shape == (1, len(x), 1) and mean.device.type == "cpu"
     n = normals[0].cpu().numpy().astype(np.float64)
     sgn = np.sign((n * G[f"{tag}_f64_n"]).sum(1))
     assert np.abs(np.abs((n * G[f"{tag}_f64_n"]).sum(1)) - 1).max() < 1e-5
     assert rel(mean[0, :, 0].numpy() * sgn, G[f"{tag}_f64_mean"]) < 1e-4
+    assert rel(jac[0].cpu().numpy() * sgn[:, None, None], G[f"{tag}_f64_shape_op"]) < 1e-4
     assert rel(gauss[0, :, 0].numpy(), G[f"{tag}_f64_gauss"]) < 1e-4
     # full shape operator + the mean from the 48-column path, through the C ABI wrapper
     lam, V, mean3, gauss3, J = hip.query_curvature(model.hip_cfg, model.flat_parameters(), x, want_shape=True, chunk=17)
