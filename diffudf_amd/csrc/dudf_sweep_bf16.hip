@@ -206,12 +206,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // MFMAs with B(c), interleaved with tail c+1 -> B(c+1) -> wait for chunk c+1 + barrier.  Tail t = pair t % NKB of
     // the layer feeding matrix t / NKB; the last step of a layer runs the first tail of the next one once its own
     // accumulators are final.
-    TailOps ops_cur, ops_n1, ops_n2;                   // pinned for the next tail / loaded one step ago / being loaded
+    TailOps ops_cur, ops_n1;                           // pinned for the next tail / in flight for the one after
     u32x4 bh, bm, bl;                                  // B operand of the current step
     f32x4 fin0 = {0, 0, 0, 0}, fin1 = {0, 0, 0, 0};    // fp32 results of pair 0 of the layer after the last matrix
     load_ops(in_layer(0), 0, ops_cur);
     load_ops(in_layer(0), 1, ops_n1);
-    load_ops(in_layer(0), 2, ops_n2);
     {
         f32x4 e0, e1;
         run_tail(in_layer(0), 0, prev[0], prev[1], ops_cur, e0, e1);
@@ -231,12 +230,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             auto frag = [&](int T, int pc) -> bf16x8 {
                 return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
             };
-            ops_cur = ops_n1; ops_n1 = ops_n2;
+            ops_cur = ops_n1;
             pin_ops(ops_cur);
             const bool more = c + 2 < total;
             if (more) dma_issue<H>(chunk_src(c + 2), lds + ((gc + 2) % 3) * G::CHUNKB, lane, wave);
-            if (kb + 3 < G::NKB) load_ops(lin, kb + 3, ops_n2);
-            else load_ops(lnx, kb + 3 - G::NKB, ops_n2);
+            if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_n1);      // operands of the tail after next: one full step ahead
+            else load_ops(lnx, kb + 2 - G::NKB, ops_n1);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 nh, nm, nl;
             // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
@@ -247,7 +246,9 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 const bf16x8 ah = an[T & 1][0], am = an[T & 1][1], al = an[T & 1][2];
                 if (T + 2 < G::NT) {
                     an[T & 1][0] = frag(T + 2, 0); an[T & 1][1] = frag(T + 2, 1); an[T & 1][2] = frag(T + 2, 2);
-                    __builtin_amdgcn_sched_barrier(0x7F);
+                    // vector/scalar ALU and vector memory may move across, LDS reads and MFMAs may not: otherwise hipcc
+                    // floats each tile's MFMAs up to its reads and every fragment is waited for just in time
+                    __builtin_amdgcn_sched_barrier(0x76);
                 }
                 f32x4 cc = acc[T];
                 cc = mfma_b(am, as_bf(bm), cc);                         // smallest terms first
@@ -258,9 +259,9 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 cc = mfma_b(ah, as_bf(bh), cc);
                 acc[T] = cc;
                 if (T == 0 && kb + 1 < G::NKB) {                        // the next step's B operand, between the MFMAs
-                    f32x4 e0, e1;
-                    run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
-                    split8(e0, e1, nh, nm, nl);
+                    f32x4 e0, e1;                                       // (spreading it over several tiles: no gain —
+                    run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);   // the SIMD's other wave
+                    split8(e0, e1, nh, nm, nl);                         //  covers the block)
                 }
             }
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
@@ -286,9 +287,9 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         for (int kb = 0; kb < G::NKB; ++kb) {
             f32x4 e0 = fin0, e1 = fin1;
             if (kb > 0) {
-                ops_cur = ops_n1; ops_n1 = ops_n2;
+                ops_cur = ops_n1;
+                if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_n1);
                 run_tail(lin, kb, prev[2 * kb], prev[2 * kb + 1], ops_cur, e0, e1);
-                if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_n2);
             }
             if constexpr (BS == SWEEP_FWD) {
                 const f32x4 w0v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 4 * q);
