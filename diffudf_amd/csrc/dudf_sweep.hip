@@ -237,7 +237,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
                     if (T + 1 < G::NT) {
                         a0n = *reinterpret_cast<const f32x4*>(bp + 16 * (T + 1));
                         a1n = *reinterpret_cast<const f32x4*>(bp + 16 * G::LDW + 16 * (T + 1));
-                        __builtin_amdgcn_sched_barrier(0x7F);   // everything but LDS ops may cross: the reads stay early
+                        __builtin_amdgcn_sched_barrier(0x76);   // VALU/SALU/VMEM may cross, LDS reads and MFMAs may not: the reads stay early
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {

@@ -18,6 +18,7 @@
 // The two thin layers (3 inputs / 1 output) are a bandwidth-bound VALU reduction.
 #include "dudf_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -377,6 +378,217 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
     }
 }
 
+// ---- bf16x6 with a COOPERATIVE split (256 x 256 tiles) ----------------------------------------------------------------
+// The kernel above is bound by vector-ALU issue, not by the matrix cores: every wave splits the fragments it consumes, so
+// an X element is split by 2 waves and a Y element by 4 (7.5 VALU instructions per MFMA, PMC).  Here every element is
+// split ONCE: a stage (16 columns x 256 features x 2 operands = 2048 16-byte granules) is dealt out 4 granules per lane
+// — four consecutive columns of one feature quad, 64 contiguous bytes of the stash — loaded straight into registers
+// (non-temporal; no raw copy in LDS), split, and written as bf16 pieces into an LDS image laid out in MFMA-FRAGMENT
+// order ([operand][piece][32-feature block][column half][feature][8 columns]: a fragment is a lane-linear 1 KiB block,
+// conflict-free for ds_read_b128).  The image is double buffered (2 x 48 KiB); one barrier per stage; the next stage's split runs in
+// front of this stage's MFMAs while the stage after that is in flight in registers.
+template <int H>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p_kernel(WgradArgs a) {
+    using W = WG<H>;
+    static_assert(H == 256, "256 x 256 output tiles");
+    constexpr int NW_ = W::WO * W::WI;
+    constexpr int FQ = H / 4;
+    constexpr int ROWB = KB * 2;                            // bytes of one feature row of a piece image: 16 columns bf16
+    constexpr int PIECEB = H * ROWB;                        // 8 KiB
+    constexpr int OPERB = 3 * PIECEB;                       // 24 KiB
+    constexpr int BUFB = 2 * OPERB;                         // 48 KiB
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];     // [2 buffers][X | Y][h | m | l][feature][16 columns]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / W::WI, wi = wave % W::WI;
+    const int j = blockIdx.x;
+    const int nsplit = gridDim.y;
+    const int steps16 = a.steps_total * (KT / KB);
+    const int s0 = (int)((int64_t)steps16 * blockIdx.y / nsplit);
+    const int s1 = (int)((int64_t)steps16 * (blockIdx.y + 1) / nsplit);
+    const int tz = a.Hs / H;
+    const int o_off = (blockIdx.z / tz) * H, i_off = (blockIdx.z % tz) * H;
+    const int64_t xrow = (int64_t)(o_off / 4) * a.np * 4, yrow = (int64_t)(i_off / 4) * a.np * 4;
+
+    f32x16 acc[W::MT][W::NTL];
+#pragma unroll
+    for (int m = 0; m < W::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < W::NTL; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer + xrow;
+    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer + xrow;
+    const float* Y0 = a.A + (int64_t)j * a.stash_layer + yrow;
+    const float* Y1 = a.S + (int64_t)j * a.stash_layer + yrow;
+
+    const int npair = a.have_g ? 2 : 1;
+    const int nit = npair * (s1 - s0);
+    auto pair_of = [&](int it) { return a.have_g ? (it & 1) : 1; };
+    auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
+
+    // producer role of this lane: operand, feature quad, group of four columns
+    const int p_oper = wave / (NW_ / 2);                                  // wave-uniform: waves 0..3 stage X, 4..7 stage Y
+    const int p_fq = (tid >> 2) & (FQ - 1), p_cg = tid & 3;
+    const int64_t p_goff = ((int64_t)p_fq * a.np + 4 * p_cg) * 4;         // floats, + col0 * 4 per stage
+    // image of one piece: [32-feature block][column half][feature in block][8 columns] = the fragment order of the MFMA
+    const int p_loff = p_oper * OPERB + (p_fq >> 3) * 1024 + (p_cg >> 1) * 512 + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
+    struct RawSet { f32x4 g0, g1, g2, g3; };                              // granule j: 4 features of column 4*cg + j
+    RawSet R0, R1, R2;                                                    // stage s travels in set s % 3, three stages ahead
+    f32x4 bacc = {0.f, 0.f, 0.f, 0.f};                                    // bias gradient partial sums (X operand, zbar pair)
+    const float* P0 = p_oper ? Y0 : X0;                                   // this wave's operand for the (q, A) / (zbar, s) pair
+    const float* P1 = p_oper ? Y1 : X1;
+    // Inline asm + hand-counted vmcnt (as in the sweeps): with compiler-visible loads hipcc drains ALL stages in flight
+    // (vmcnt(0)) at the loop head.  These twelve loads are the only vector-memory operations of the loop.
+    auto load_raw = [&](int it, RawSet& r) {
+        const float* src = (pair_of(it) ? P1 : P0) + p_goff + (int64_t)step_of(it) * KB * 4;
+        asm volatile("global_load_dwordx4 %0, %4, off nt\n\tglobal_load_dwordx4 %1, %4, off offset:16 nt\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32 nt\n\tglobal_load_dwordx4 %3, %4, off offset:48 nt"
+                     : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3) : "v"(src) : "memory");
+    };
+    // outside the steady-state loop (prologue, last stages: conditional loads) the loads are ordinary ones: a conditional
+    // asm load makes hipcc merge "loaded" and "not loaded" values with register copies — of registers still in flight
+    auto load_raw_plain = [&](int it, RawSet& r) {
+        const float* src = (pair_of(it) ? P1 : P0) + p_goff + (int64_t)step_of(it) * KB * 4;
+        r.g0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+        r.g1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 1);
+        r.g2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 2);
+        r.g3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 3);
+    };
+    auto wait_raw = [&](RawSet& r, auto younger) {       // this set has landed; `younger` loads issued after it stay in flight
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.g0), "+v"(r.g1), "+v"(r.g2), "+v"(r.g3) : "n"(decltype(younger)::value));
+    };
+    auto split_store = [&](int it, const RawSet& r) {                     // raw (stage it) -> piece image buffer it & 1
+        const f32x4 raw0 = r.g0, raw1 = r.g1, raw2 = r.g2, raw3 = r.g3;
+        char* dst = ldsb + (it & 1) * BUFB + p_loff;
+        const bool hstage = (int64_t)step_of(it) * KB < a.ncol_h;         // Hessian quads: only columns % 4 == 0 carry the bias
+        const float bm = (p_oper == 0 && pair_of(it) == 1 && i_off == 0) ? 1.f : 0.f;
+        const float bo = hstage ? 0.f : bm;
+        bacc += bm * raw0 + bo * (raw1 + raw2 + raw3);
+        auto one = [&](float c0, float c1, float c2, float c3, char* d) {   // four columns of one feature -> 3 x 8 bytes
+            const f32x2 v0 = {c0, c1}, v1 = {c2, c3};
+            const unsigned h0 = cvt_pk(v0), h1 = cvt_pk(v1);
+            const f32x2 r0 = v0 - unpack(h0), r1 = v1 - unpack(h1);
+            const unsigned m0 = cvt_pk(r0), m1 = cvt_pk(r1);
+            const f32x2 q0 = r0 - unpack(m0), q1 = r1 - unpack(m1);
+            const unsigned l0 = cvt_pk(q0), l1 = cvt_pk(q1);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + PIECEB) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * PIECEB) = u32x2{l0, l1};
+        };
+        one(raw0.x, raw1.x, raw2.x, raw3.x, dst);
+        one(raw0.y, raw1.y, raw2.y, raw3.y, dst + 16);
+        one(raw0.z, raw1.z, raw2.z, raw3.z, dst + 32);
+        one(raw0.w, raw1.w, raw2.w, raw3.w, dst + 48);
+    };
+    // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
+    const int c_lane = lane * 16;
+    auto fragA = [&](const char* buf, int m, int pc) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(buf + pc * PIECEB + (wo * W::MT + m) * 1024 + c_lane);
+    };
+    auto fragB = [&](const char* buf, int n, int pc) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * 1024 + c_lane);
+    };
+
+    if (nit > 0) {
+        load_raw_plain(0, R0);
+        split_store(0, R0);
+        if (nit > 1) load_raw_plain(1, R1);
+        if (nit > 2) load_raw_plain(2, R2);
+        if (nit > 3) load_raw_plain(3, R0);
+    }
+    __syncthreads();
+    // one stage: the next stage's registers -> pieces (its set is then refilled with the stage three further on, so three
+    // stages = 96 KiB per CU stay in flight: with one, the kernel measured latency-bound at 2 TB/s), then 48 MFMAs
+    auto stage = [&](int it, RawSet& r, auto hot) {
+        const char* buf = ldsb + (it & 1) * BUFB;
+        if constexpr (decltype(hot)::value) {     // steady state: the two younger sets (8 loads) stay in flight
+            wait_raw(r, std::integral_constant<int, 8>{});
+            split_store(it + 1, r);
+            load_raw(it + 4, r);
+        } else if (it + 1 < nit) {
+            split_store(it + 1, r);
+            if (it + 4 < nit) load_raw_plain(it + 4, r);
+        }
+        bf16x8 af[W::MT][3], bn[3];
+#pragma unroll
+        for (int m = 0; m < W::MT; ++m)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) af[m][pc] = fragA(buf, m, pc);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, 0, pc);
+#pragma unroll
+        for (int n = 0; n < W::NTL; ++n) {
+            const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
+            if (n + 1 < W::NTL) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n + 1, pc);
+                __builtin_amdgcn_sched_barrier(0x76);            // LDS reads and MFMAs keep their order: fragments one block ahead
+            }
+#pragma unroll
+            for (int m = 0; m < W::MT; ++m) {
+                f32x16 c = acc[m][n];
+                c = mfma_bf16(af[m][1], bmid, c);                 // smallest terms first
+                c = mfma_bf16(af[m][2], bh, c);
+                c = mfma_bf16(af[m][0], bl, c);
+                c = mfma_bf16(af[m][1], bh, c);
+                c = mfma_bf16(af[m][0], bmid, c);
+                c = mfma_bf16(af[m][0], bh, c);
+                acc[m][n] = c;
+            }
+        }
+        __syncthreads();
+    };
+    int it = 0;                                                  // stage it+1 lives in set (it+1) % 3
+    const int nhot = nit >= 7 ? ((nit - 4) / 3) * 3 : 0;
+    // hipcc does not know the sets are in flight: enter (and leave) the hand-counted loop with everything landed, so that
+    // the register copies it places on the loop's edges are harmless; inside, the sets stay put (tests/isa_contract.py
+    // replays the loop body twice and fails on any instruction that touches a register with a load in flight)
+    auto drain = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0.g0), "+v"(R0.g1), "+v"(R0.g2), "+v"(R0.g3), "+v"(R1.g0), "+v"(R1.g1),
+                     "+v"(R1.g2), "+v"(R1.g3), "+v"(R2.g0), "+v"(R2.g1), "+v"(R2.g2), "+v"(R2.g3));
+    };
+    drain();
+    for (; it < nhot; it += 3) {
+        stage(it, R1, std::true_type{});
+        stage(it + 1, R2, std::true_type{});
+        stage(it + 2, R0, std::true_type{});
+    }
+    drain();
+    for (; it < nit; it += 3) {
+        stage(it, R1, std::false_type{});
+        if (it + 1 < nit) stage(it + 1, R2, std::false_type{});
+        if (it + 2 < nit) stage(it + 2, R0, std::false_type{});
+    }
+
+    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)o_off * a.Hs + i_off;
+    float* dB = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)a.Hs * a.Hs + o_off;
+    if (nit > 0) {
+        const int l32 = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int m = 0; m < W::MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int o = (wo * W::MT + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+                for (int n = 0; n < W::NTL; ++n) {
+                    const int i = (wi * W::NTL + n) * 32 + l32;
+                    atomicAdd(dW + (int64_t)o * a.Hs + i, acc[m][n][e]);
+                }
+            }
+        if (p_oper == 0 && i_off == 0) {                          // bias gradient: sum the four column groups of a quad first
+            auto red = [&](float v, int f) {
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                if (p_cg == 0) atomicAdd(dB + 4 * p_fq + f, v);
+            };
+            red(bacc.x, 0); red(bacc.y, 1); red(bacc.z, 2); red(bacc.w, 3);
+        }
+    }
+}
+
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
 //   dW_1[o][d] | db_1[o] = sum_c  q_1[o][c] * gbar[c][d]  +  zbar_1[o][c] * x4[c][d]      (d = 3 is the bias: x4[c][3])
 //   dW_out[f]            = sum_c  A_L[f][c] * x4[c][3]   +  ybar[c] * s_L[f][c]
@@ -484,6 +696,22 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bf);
             if (e != hipSuccess) return (int)e;
             attr2 = true;
+        }
+        // DUDF_WGRAD=bf16w keeps the per-wave split kernel for the 256-wide tiles (A/B testing)
+        static const bool per_wave = [] { const char* e = getenv("DUDF_WGRAD"); return e && e[0] == 'b' && e[4] == 'w'; }();
+        if constexpr (H == 256) {
+            if (!per_wave) {
+                static bool attr3 = false;
+                const size_t smem_p = 2 * 2 * 3 * (size_t)H * KB * 2;             // 2 buffers x (X | Y) x 3 pieces x H x 16 bf16
+                if (!attr3) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+                    if (e != hipSuccess) return (int)e;
+                    attr3 = true;
+                }
+                hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a);
+                return (int)hipGetLastError();
+            }
         }
         hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_bf, st, a);
     }

@@ -87,3 +87,47 @@ def analyse_bf16(asm_path, ndma=6):
                 dma = other = 0
         out[(int(m.group(2)), int(m.group(3)))] = {"steps": steps, "idle": idle, "scratch": scratch}
     return out
+
+
+def _vregs(tok):
+    out = set()
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", tok):
+        out |= set(range(int(a), int(b) + 1))
+    for a in re.findall(r"(?<![\[\w])v(\d+)(?![\d:\]])", tok):
+        out.add(int(a))
+    return out
+
+
+def analyse_wgrad_presplit(asm_path):
+    """wgrad_hidden_bf16p_kernel<256> stages the stash through REGISTERS with inline-asm loads and hand-counted vmcnt
+    waits (hipcc does not know those registers are in flight).  Walks every basic block of the kernel in text order with a
+    FIFO of the asm loads and returns the instructions that touch a destination register of a load still in flight
+    (must be none), plus the number of asm loads seen."""
+    txt = open(asm_path).read()
+    m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256E\w*):", txt, re.M)
+    body = txt[m.end():txt.index("s_endpgm", m.end())].split("\n")
+    fifo, bad, nloads, in_asm = [], [], 0, False
+    for ln in body:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t[0] in ";.":
+            continue
+        if in_asm and t.startswith("global_load_dwordx4"):
+            fifo.append(_vregs(t.split(",")[0]))
+            nloads += 1
+            continue
+        if t.startswith("s_waitcnt") and "vmcnt" in t:
+            n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+            while len(fifo) > n:
+                fifo.pop(0)
+            continue
+        pend = set().union(*fifo) if fifo else set()
+        hit = _vregs(t) & pend
+        if hit and not t.startswith("global_load_dwordx4"):
+            bad.append((t, sorted(hit)))
+    return {"bad": bad, "loads": nloads}
