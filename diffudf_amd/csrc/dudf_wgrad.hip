@@ -384,8 +384,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
 // split ONCE: a stage (16 columns x 256 features x 2 operands = 2048 16-byte granules) is dealt out 4 granules per lane
 // — four consecutive columns of one feature quad, 64 contiguous bytes of the stash — loaded straight into registers
 // (non-temporal; no raw copy in LDS), split, and written as bf16 pieces into an LDS image laid out in MFMA-FRAGMENT
-// order ([operand][piece][32-feature block][column half][feature][8 columns]: a fragment is a lane-linear 1 KiB block,
-// conflict-free for ds_read_b128).  The image is double buffered (2 x 48 KiB); one barrier per stage; the next stage's split runs in
+// order ([operand][piece][32-feature block][column half][feature][8 columns]: a fragment is two lane-linear 512-byte
+// halves, conflict-free for ds_read_b128; the halves are 528 bytes apart so that the 8-byte writes do not collide).  The image is double buffered (2 x 48 KiB); one barrier per stage; the next stage's split runs in
 // front of this stage's MFMAs while the stage after that is in flight in registers.
 template <int H>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p_kernel(WgradArgs a) {
@@ -393,8 +393,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     static_assert(H == 256, "256 x 256 output tiles");
     constexpr int NW_ = W::WO * W::WI;
     constexpr int FQ = H / 4;
-    constexpr int ROWB = KB * 2;                            // bytes of one feature row of a piece image: 16 columns bf16
-    constexpr int PIECEB = H * ROWB;                        // 8 KiB
+    constexpr int HALFB = 32 * 16 + 16;                     // 32 features x 8 columns of a block, +16: the second column half
+    constexpr int BLKB = 2 * HALFB;                         //   must not sit 512 B = 0 banks after the first (ds_write_b64)
+    constexpr int PIECEB = (H / 32) * BLKB;                 // 8.25 KiB
     constexpr int OPERB = 3 * PIECEB;                       // 24 KiB
     constexpr int BUFB = 2 * OPERB;                         // 48 KiB
     extern __shared__ __attribute__((aligned(16))) char ldsb[];     // [2 buffers][X | Y][h | m | l][feature][16 columns]
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     const int p_fq = (tid >> 2) & (FQ - 1), p_cg = tid & 3;
     const int64_t p_goff = ((int64_t)p_fq * a.np + 4 * p_cg) * 4;         // floats, + col0 * 4 per stage
     // image of one piece: [32-feature block][column half][feature in block][8 columns] = the fragment order of the MFMA
-    const int p_loff = p_oper * OPERB + (p_fq >> 3) * 1024 + (p_cg >> 1) * 512 + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
+    const int p_loff = p_oper * OPERB + (p_fq >> 3) * BLKB + (p_cg >> 1) * HALFB + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
     struct RawSet { f32x4 g0, g1, g2, g3; };                              // granule j: 4 features of column 4*cg + j
     RawSet R0, R1, R2;                                                    // stage s travels in set s % 3, three stages ahead
     f32x4 bacc = {0.f, 0.f, 0.f, 0.f};                                    // bias gradient partial sums (X operand, zbar pair)
@@ -484,12 +485,12 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
         one(raw0.w, raw1.w, raw2.w, raw3.w, dst + 48);
     };
     // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
-    const int c_lane = lane * 16;
+    const int c_lane = (lane >> 5) * HALFB + (lane & 31) * 16;
     auto fragA = [&](const char* buf, int m, int pc) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(buf + pc * PIECEB + (wo * W::MT + m) * 1024 + c_lane);
+        return *reinterpret_cast<const bf16x8*>(buf + pc * PIECEB + (wo * W::MT + m) * BLKB + c_lane);
     };
     auto fragB = [&](const char* buf, int n, int pc) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * 1024 + c_lane);
+        return *reinterpret_cast<const bf16x8*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
     };
 
     if (nit > 0) {
@@ -702,7 +703,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
         if constexpr (H == 256) {
             if (!per_wave) {
                 static bool attr3 = false;
-                const size_t smem_p = 2 * 2 * 3 * (size_t)H * KB * 2;             // 2 buffers x (X | Y) x 3 pieces x H x 16 bf16
+                const size_t smem_p = 2 * 2 * 3 * (size_t)(H / 32) * 2 * (32 * 16 + 16);   // 2 buffers x (X | Y) x 3 pieces x blocks
                 if (!attr3) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);

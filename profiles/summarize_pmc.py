@@ -29,9 +29,9 @@ def kname(k):
     if "sweep_kernel" in k:
         sig = k.split("sweep_kernel")[1].split("(")[0]
         return NAMES.get(sig, "sweep" + sig) + "_f32"
-    for n in ("wgrad_hidden_bf16", "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel", "pack_kernel"):
+    for n in ("wgrad_hidden_bf16p", "wgrad_hidden_bf16", "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel", "pack_kernel"):
         if n in k:
-            return n.replace("_kernel", "").replace("wgrad_hidden_bf16", "wgrad_hidden")
+            return n.replace("_kernel", "").replace("wgrad_hidden_bf16p", "wgrad_hidden").replace("wgrad_hidden_bf16", "wgrad_hidden")
     return None
 
 

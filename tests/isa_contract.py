@@ -100,34 +100,57 @@ def _vregs(tok):
 
 def analyse_wgrad_presplit(asm_path):
     """wgrad_hidden_bf16p_kernel<256> stages the stash through REGISTERS with inline-asm loads and hand-counted vmcnt
-    waits (hipcc does not know those registers are in flight).  Walks every basic block of the kernel in text order with a
-    FIFO of the asm loads and returns the instructions that touch a destination register of a load still in flight
-    (must be none), plus the number of asm loads seen."""
+    waits inside its steady-state loop (hipcc does not know those registers are in flight).  Finds that loop (the
+    self-looping basic block that holds the MFMAs and the asm loads), replays it twice with a FIFO of the loads — the
+    second pass starts with what the first left in flight — and returns the instructions that touch a destination
+    register of a load still in flight (must be none), the loads per pass and the loads in flight across the back edge."""
     txt = open(asm_path).read()
     m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256E\w*):", txt, re.M)
     body = txt[m.end():txt.index("s_endpgm", m.end())].split("\n")
-    fifo, bad, nloads, in_asm = [], [], 0, False
+    blocks, cur, name = [], [], "entry"
     for ln in body:
         t = ln.strip()
-        if t.startswith(";;#ASMSTART"):
-            in_asm = True
-            continue
-        if t.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        if not t or t[0] in ";.":
-            continue
-        if in_asm and t.startswith("global_load_dwordx4"):
-            fifo.append(_vregs(t.split(",")[0]))
-            nloads += 1
-            continue
-        if t.startswith("s_waitcnt") and "vmcnt" in t:
-            n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
-            while len(fifo) > n:
-                fifo.pop(0)
-            continue
-        pend = set().union(*fifo) if fifo else set()
-        hit = _vregs(t) & pend
-        if hit and not t.startswith("global_load_dwordx4"):
-            bad.append((t, sorted(hit)))
-    return {"bad": bad, "loads": nloads}
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            blocks.append((name, cur))
+            name, cur = t.split(":")[0], []
+        else:
+            cur.append(t)
+    blocks.append((name, cur))
+    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= 100
+           and any(x.startswith("global_load_dwordx4") for x in b)]
+    assert len(hot) == 1, [n for n, _ in hot]
+    name, blk = hot[0]
+    assert any(x.startswith("s_cbranch") and x.endswith(name) for x in blk), "the hot block must loop onto itself"
+
+    def replay(fifo):
+        bad, loads, in_asm = [], 0, False
+        for t in blk:
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            if t.startswith("global_load_dwordx4"):
+                assert in_asm, "a compiler-issued load inside the hand-counted loop: " + t
+                fifo.append(_vregs(t.split(",")[0]))
+                loads += 1
+                continue
+            if t.startswith("s_waitcnt") and "vmcnt" in t:
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                while len(fifo) > n:
+                    fifo.pop(0)
+                continue
+            pend = set().union(*fifo) if fifo else set()
+            hit = _vregs(t) & pend
+            if hit:
+                bad.append((t, sorted(hit)))
+        return bad, loads
+
+    fifo = []
+    bad1, loads = replay(fifo)
+    carried = len(fifo)
+    bad2, _ = replay(fifo)
+    return {"bad": bad1 + bad2, "loads": loads, "carried": carried}

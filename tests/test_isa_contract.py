@@ -8,7 +8,7 @@ import pytest
 
 import sys, os as _os
 sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-from isa_contract import analyse, analyse_bf16, emit_asm
+from isa_contract import analyse, analyse_bf16, analyse_wgrad_presplit, emit_asm
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -48,3 +48,14 @@ def test_bf16_sweep_wait_counts(tmp_path):
         for dma, ops, n in steady:
             assert n == 2 * ops + dma, (key, dma, ops, n)          # and not needlessly small either
         assert any(s == (6, 0, 6) or s[2] == 6 for s in v["steps"]) or v["idle"], key     # the idle-wave loop's vmcnt(NDMA)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_wgrad_register_staging_contract(tmp_path):
+    """dudf_wgrad.hip, cooperative-split kernel: three stages (12 loads) travel in registers across the loop's back edge
+    behind hand-counted waits; no instruction may read or write such a register before its wait."""
+    asm = str(tmp_path / "wgrad.s")
+    emit_asm(os.path.join(REPO, "diffudf_amd", "csrc", "dudf_wgrad.hip"), asm)
+    res = analyse_wgrad_presplit(asm)
+    assert res["loads"] == 12 and res["carried"] == 12, res
+    assert not res["bad"], res["bad"][:5]
