@@ -60,6 +60,21 @@ def main():
                       "value": M / dt, "unit": "points/s", "points": M, "seconds": dt,
                       "tflops_fp32_mfma": 24 * F0 * M / dt / 1e12,
                       "config": "BASELINE configs[3]: src/render_st.py compute_normals_and_cd + compute_curvature on 512^2 ray points"}))
+    # sphere tracing: 512^2 rays from the plane z = 0.95 into the domain, 100 marching iterations (configs/st_mean_cfg.json)
+    side = args.rays
+    g = torch.linspace(-0.9, 0.9, side, dtype=torch.float64)
+    gx, gy = torch.meshgrid(g, g, indexing="ij")
+    t0 = torch.stack([gx.reshape(-1), gy.reshape(-1), torch.full((M,), 0.95, dtype=torch.float64)], 1).cuda().contiguous()
+    rays = torch.tensor([[0.0, 0.0, -1.0]], dtype=torch.float64).repeat(M, 1).cuda().contiguous()
+    for rep in range(2):
+        tt, mk = t0.clone(), torch.ones(M, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        hits, iters = hip_ops.trace_rays(cfg, model.flat_parameters(), rays, tt, mk, "tanh", 100, 0.004, 100)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t1
+    print(json.dumps({"metric": "sphere-tracing ray-iterations/sec (value query + inverse + masks, on device)",
+                      "value": M * iters / dt, "unit": "ray-iterations/s", "rays": M, "iterations": iters, "seconds": dt,
+                      "hits": int(hits.sum()),
+                      "config": "BASELINE configs[3]: src/render_st.py propagate_rays, 512^2 rays, max_iterations 100"}))
 
 
 if __name__ == "__main__":

@@ -43,6 +43,11 @@ SYMBOLS = {
     "dudf_query_frame": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_workspace_bytes_curvature": (ctypes.c_size_t, [_CFG, ctypes.c_int64]),
     "dudf_query_curvature": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_trace_rays": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _P,
+                                       ctypes.c_size_t, _P]),
+    "dudf_descend_rays": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_int, _P, ctypes.c_size_t, _P]),
     "dudf_grid_fields": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_double, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_query": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),

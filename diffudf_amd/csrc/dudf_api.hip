@@ -255,6 +255,57 @@ int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const floa
     return (int)e;
 }
 
+int dudf_trace_rays(const dudf_net_cfg* cfg, const float* theta, const double* rays, double* t0, unsigned char* mask,
+                    unsigned char* hits, int64_t m, int inverse_mode, double alpha, double min_step,
+                    double surface_threshold, int max_iterations, int check_every, int* iterations_done,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (inverse_mode < 0 || inverse_mode > 2 || max_iterations < 0 || check_every < 1) return DUDF_E_BADMODE;
+    Ctx c;
+    int rc = open_ctx(cfg, m, 0, workspace, workspace_bytes, stream, &c, 1);
+    if (rc) return rc;
+    if (iterations_done) *iterations_done = 0;
+    if (m <= 0) return 0;
+    hipError_t e = hipMemsetAsync(hits, 0, (size_t)m, c.st);
+    if (e != hipSuccess) return (int)e;
+    if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
+    if (use_bf16_sweeps() && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
+    SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
+    int* active = reinterpret_cast<int*>(c.ws + c.lo.ws_acc);
+    int it = 0;
+    for (; it < max_iterations; ++it) {
+        // value-only queries at the current positions of ALL rays (retired ones are evaluated and ignored: no compaction,
+        // no per-iteration host round trip), then the step / hit / retire update of the active ones
+        if ((rc = dudf_launch_rays_x4(c.lo, t0, c.ws, c.st))) return rc;
+        if ((rc = run_sweep(SWEEP_FWD, c.lo, a, c.st))) return rc;
+        if ((rc = dudf_launch_rays_step(c.lo, c.ws, rays, t0, mask, hits, inverse_mode, alpha, min_step, surface_threshold,
+                                        active, c.st))) return rc;
+        if ((it + 1) % check_every == 0 || it + 1 == max_iterations) {   // the reference's `while np.sum(mask_rays) > 0`
+            int left = 0;
+            if ((e = hipMemcpyAsync(&left, active, sizeof(int), hipMemcpyDeviceToHost, c.st)) != hipSuccess) return (int)e;
+            if ((e = hipStreamSynchronize(c.st)) != hipSuccess) return (int)e;
+            if (left == 0) { ++it; break; }
+        }
+    }
+    if (iterations_done) *iterations_done = it;
+    return 0;
+}
+
+int dudf_descend_rays(const dudf_net_cfg* cfg, const float* theta, double* t0, const unsigned char* hits, int64_t m,
+                      int inverse_mode, double alpha, double min_step, int gd_steps, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (inverse_mode < 0 || inverse_mode > 2 || gd_steps < 0) return DUDF_E_BADMODE;
+    Ctx c;
+    int rc = open_ctx(cfg, m, 0, workspace, workspace_bytes, stream, &c, 1);
+    if (rc) return rc;
+    if (m <= 0) return 0;
+    for (int s = 0; s < gd_steps; ++s) {
+        if ((rc = dudf_launch_rays_x4(c.lo, t0, c.ws, c.st))) return rc;
+        if ((rc = forward_common(c, theta, nullptr, 0, true))) return rc;
+        if ((rc = dudf_launch_rays_descend(c.lo, c.ws, t0, hits, inverse_mode, alpha, min_step, c.st))) return rc;
+    }
+    return 0;
+}
+
 int dudf_grid_fields(const dudf_net_cfg* cfg, const float* theta, int64_t grid_n, int64_t start, int64_t count,
                      int inverse_mode, double alpha, float* out_df, float* out_vec, int* out_flag_count,
                      void* workspace, size_t workspace_bytes, void* stream) {

@@ -142,6 +142,13 @@ int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, in
 int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st);
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, float* out_h,
                          hipStream_t st);
+// sphere tracing (reference src/render_st.py:136-172): x4 from double positions, one marching / descent iteration
+int dudf_launch_rays_x4(const DudfLayout& lo, const double* t0, float* ws, hipStream_t st);
+int dudf_launch_rays_step(const DudfLayout& lo, const float* ws, const double* rays, double* t0, unsigned char* mask,
+                          unsigned char* hits, int inverse_mode, double alpha, double min_step, double threshold,
+                          int* active, hipStream_t st);
+int dudf_launch_rays_descend(const DudfLayout& lo, const float* ws, double* t0, const unsigned char* hits,
+                             int inverse_mode, double alpha, double min_step, hipStream_t st);
 // third-order jets: x4 of n points x one 16-column tile (value + the eigen-frame V as three directions), and the
 // epilogue that turns the jets' mixed third-order coefficients into curvature
 int dudf_launch_make_x4_jet(const float* x, const float* V, int64_t n, int64_t npj, float* x4j, hipStream_t st);

@@ -512,6 +512,67 @@ __global__ __launch_bounds__(256) void curvature_kernel(const float* __restrict_
     }
 }
 
+// ---- sphere tracing on the device (reference src/render_st.py:136-172 `propagate_rays`, `grad_descent`) ----------------
+// The reference keeps ray positions in float64 numpy, feeds float32 copies to the network, takes the step in float32
+// (`inverse`, src/inverses.py:3-21) and adds it in float64.  Same here: t0 is double, x4 = (float)t0, the step float.
+__device__ __forceinline__ float inverse_step(float f, int inverse_mode, float alpha, float min_step) {
+    if (inverse_mode == 0) return (f < 1.0f / alpha) ? sqrtf(f / alpha) : f;               // 'tanh'
+    if (inverse_mode == 1) return (f > 0.f) ? f : min_step;                               // 'siren'
+    return ((f > 0.f) ? sqrtf(f) : min_step) / sqrtf(alpha);                              // 'squared'
+}
+
+__global__ __launch_bounds__(256) void rays_x4_kernel(const double* __restrict__ t0, int64_t m, int64_t np,
+                                                      float* __restrict__ x4) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p < m) v = f32x4{(float)t0[p * 3], (float)t0[p * 3 + 1], (float)t0[p * 3 + 2], 1.f};
+        *reinterpret_cast<f32x4*>(x4 + p * 4) = v;
+    }
+}
+
+// one marching iteration for the rays still active: step along the ray, record hits, retire rays (:141-156)
+__global__ __launch_bounds__(256) void rays_step_kernel(const float* __restrict__ y, const double* __restrict__ rays,
+                                                        double* __restrict__ t0, unsigned char* __restrict__ mask,
+                                                        unsigned char* __restrict__ hits, int64_t m, int inverse_mode,
+                                                        float alpha, float min_step, float threshold,
+                                                        int* __restrict__ active) {
+    int mine = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < m; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!mask[p]) continue;
+        const float udf = y[p];
+        const float step = inverse_step(fabsf(udf), inverse_mode, alpha, min_step);
+        double q[3];
+        bool inside = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            q[k] = t0[p * 3 + k] + rays[p * 3 + k] * (double)step;
+            t0[p * 3 + k] = q[k];
+            inside = inside && q[k] > -1.0 && q[k] < 1.0;
+        }
+        const bool close = (inverse_mode == 1) ? (udf < threshold) : (fabsf(step) < threshold);
+        if (close && inside) hits[p] = 1;
+        const bool go_on = !close && inside;
+        mask[p] = go_on ? 1 : 0;
+        mine += go_on ? 1 : 0;
+    }
+    if (mine) atomicAdd(active, mine);
+}
+
+// one descent step for the hit rays: t0 -= normalize(grad f) * inverse(|f|)  (:163-172; src/util.py:35-40 `normalize`)
+__global__ __launch_bounds__(256) void rays_descend_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                           double* __restrict__ t0, const unsigned char* __restrict__ hits,
+                                                           int64_t m, int inverse_mode, float alpha, float min_step) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < m; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!hits[p]) continue;
+        const float gx = g[p * 4], gy = g[p * 4 + 1], gz = g[p * 4 + 2];
+        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+        const float step = inverse_step(fabsf(y[p]), inverse_mode, alpha, min_step);
+        t0[p * 3] -= (double)((gx / nrm) * step);
+        t0[p * 3 + 1] -= (double)((gy / nrm) * step);
+        t0[p * 3 + 2] -= (double)((gz / nrm) * step);
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -632,6 +693,31 @@ int dudf_launch_curvature(const float* yj, const float* lam, const float* V, int
     DudfProfScope prof(PROF_OTHER, st);
     hipLaunchKernelGGL(curvature_kernel, dim3(grid_for(n)), dim3(256), 0, st, yj, lam, V, n, out_mean, out_gauss,
                        out_shape);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_rays_x4(const DudfLayout& lo, const double* t0, float* ws, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(rays_x4_kernel, dim3(grid_for(lo.np)), dim3(256), 0, st, t0, lo.n, lo.np, ws + lo.ws_x4);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_rays_step(const DudfLayout& lo, const float* ws, const double* rays, double* t0, unsigned char* mask,
+                          unsigned char* hits, int inverse_mode, double alpha, double min_step, double threshold,
+                          int* active, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipError_t e = hipMemsetAsync(active, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(rays_step_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, rays, t0, mask, hits, lo.n,
+                       inverse_mode, (float)alpha, (float)min_step, (float)threshold, active);
+    return (int)hipGetLastError();
+}
+
+int dudf_launch_rays_descend(const DudfLayout& lo, const float* ws, double* t0, const unsigned char* hits,
+                             int inverse_mode, double alpha, double min_step, hipStream_t st) {
+    DudfProfScope prof(PROF_OTHER, st);
+    hipLaunchKernelGGL(rays_descend_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, ws + lo.ws_y, ws + lo.ws_g, t0, hits,
+                       lo.n, inverse_mode, (float)alpha, (float)min_step);
     return (int)hipGetLastError();
 }
 

@@ -168,6 +168,36 @@ def query_curvature(cfg, theta, x, want_shape=False, chunk=65536):
 INVERSE_MODES = {"tanh": 0, "siren": 1, "squared": 2}
 
 
+def trace_rays(cfg, theta, rays, t0, mask, gt_mode, alpha, surface_threshold, max_iterations, check_every=8, min_step=0.01):
+    """The marching loop of reference src/render_st.py:136-161 on the device.  rays (m,3), t0 (m,3) float64 CUDA tensors,
+    mask (m,) uint8; t0 and mask are updated in place.  Returns (hits (m,) uint8, iterations executed)."""
+    lib = _lib.load()
+    theta = _f32(theta, "theta")
+    m = t0.shape[0]
+    for t, dt in ((rays, torch.float64), (t0, torch.float64), (mask, torch.uint8)):
+        if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+            raise _lib.DudfError("trace_rays: rays/t0 must be contiguous float64 CUDA tensors, mask uint8")
+    hits = torch.empty(m, dtype=torch.uint8, device=t0.device)
+    ws = query_workspace_for(cfg, m, t0.device)
+    done = ctypes.c_int(0)
+    rc = lib.dudf_trace_rays(ctypes.byref(cfg), _ptr(theta), _ptr(rays), _ptr(t0), _ptr(mask), _ptr(hits), m,
+                             INVERSE_MODES[gt_mode], float(alpha), float(min_step), float(surface_threshold),
+                             int(max_iterations), int(check_every), ctypes.byref(done), _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_trace_rays")
+    return hits, done.value
+
+
+def descend_rays(cfg, theta, t0, hits, gt_mode, alpha, gd_steps, min_step=0.01):
+    """`grad_descent` of reference src/render_st.py:163-172 on the device; t0 (m,3) float64 updated in place."""
+    lib = _lib.load()
+    theta = _f32(theta, "theta")
+    m = t0.shape[0]
+    ws = query_workspace_for(cfg, m, t0.device)
+    rc = lib.dudf_descend_rays(ctypes.byref(cfg), _ptr(theta), _ptr(t0), _ptr(hits), m, INVERSE_MODES[gt_mode],
+                               float(alpha), float(min_step), int(gd_steps), _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_descend_rays")
+
+
 def grid_fields(cfg, theta, grid_n, start, count, gt_mode, alpha, out_df, out_vec, ws=None):
     """Fills out_df[start:start+count], out_vec[start:start+count] (device tensors over the flattened N^3 grid);
     returns the device int32 counter of points that need the Hessian-eigenvector fallback."""

@@ -1,7 +1,9 @@
 # coding: utf-8
 """Differential quantities the sphere tracer derives at ray hits — the query half of reference
-src/render_st.py:42-65 (BASELINE config 4).  The ray marching / shading loop (:67-281) is outside this build's
-scope."""
+src/render_st.py:42-65 (BASELINE config 4).  The marching loop itself (`propagate_rays`, `grad_descent`, :136-172)
+runs on the device too; ray set-up and shading (numpy glue) stay with the caller."""
+import numpy as np
+import torch
 import weakref
 
 from . import hip_ops
@@ -41,3 +43,42 @@ def compute_curvature(inputs, normals, curvature='mean', device=None):
                                                    want_shape=(curvature == 'gaussian'))
     out = mean if curvature == 'mean' else gauss
     return out.detach().cpu()[None, ..., None]
+
+
+def _device_of(model, device):
+    return torch.device(device) if device is not None else model.flat_parameters().device
+
+
+def propagate_rays(model, rays, t0, mask_rays, network_config, rendering_config, device=None):
+    """reference src/render_st.py:136-161, same signature and in-place contract: `t0` (M,3) float64 and `mask_rays` (M,)
+    bool numpy arrays are updated, the bool hit mask is returned.  One upload, `max_iterations` marching iterations on
+    the GPU (a host round trip every 8 of them for the `np.sum(mask_rays) > 0` test, not three copies per iteration),
+    one download."""
+    dev = _device_of(model, device)
+    d_rays = torch.from_numpy(np.ascontiguousarray(rays, dtype=np.float64)).to(dev)
+    d_t0 = torch.from_numpy(np.ascontiguousarray(t0, dtype=np.float64)).to(dev)
+    d_mask = torch.from_numpy(np.ascontiguousarray(mask_rays).astype(np.uint8)).to(dev)
+    with torch.cuda.device(dev):
+        hits, _ = hip_ops.trace_rays(model.hip_cfg, model.flat_parameters(), d_rays, d_t0, d_mask,
+                                     network_config['gt_mode'], network_config['alpha'],
+                                     rendering_config['surface_threshold'], rendering_config['max_iterations'])
+    t0[...] = d_t0.cpu().numpy()
+    mask_rays[...] = d_mask.cpu().numpy().astype(bool)
+    hits = hits.cpu().numpy().astype(bool)
+    if np.sum(hits) == 0:
+        raise ValueError(f"Ray tracing did not converge in {rendering_config['max_iterations']} iterations to any point at "
+                         f"distance {rendering_config['surface_threshold']} or lower from surface.")
+    return hits
+
+
+def grad_descent(model, t0, mask_rays, network_config, rendering_config, device=None):
+    """reference src/render_st.py:163-172: `gd_steps` projection steps of the hit points, in place on `t0`."""
+    if rendering_config['gd_steps'] <= 0:
+        return
+    dev = _device_of(model, device)
+    d_t0 = torch.from_numpy(np.ascontiguousarray(t0, dtype=np.float64)).to(dev)
+    d_hits = torch.from_numpy(np.ascontiguousarray(mask_rays).astype(np.uint8)).to(dev)
+    with torch.cuda.device(dev):
+        hip_ops.descend_rays(model.hip_cfg, model.flat_parameters(), d_t0, d_hits, network_config['gt_mode'],
+                             network_config['alpha'], rendering_config['gd_steps'])
+    t0[...] = d_t0.cpu().numpy()

@@ -87,6 +87,23 @@ int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const floa
                          float* out_lambda, float* out_v, float* out_mean, float* out_gauss, float* out_shape,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sphere tracing on the device — replaces the loop of `propagate_rays` (reference src/render_st.py:136-161: per iteration
+ * a value-only `evaluate`, `inverse(gt_mode, |f|, alpha)` (src/inverses.py), `t0 += rays * steps`, threshold / in-domain
+ * masks, one D2H copy) for m rays.  rays (m,3) and t0 (m,3) are float64 like the reference's numpy arrays (the network
+ * sees float32 copies, the step is taken in float32 and added in float64); mask (m) 0/1 bytes = `mask_rays` in/out,
+ * hits (m) 0/1 bytes out.  The active-ray count is read back only every `check_every` iterations; iterations past the
+ * point where no ray is active change nothing.  *iterations_done (host) = iterations executed.  The reference raises if
+ * no ray hit; the caller checks hits.  inverse_mode 0 'tanh' / 1 'siren' / 2 'squared'; min_step = 0.01 there.
+ * workspace: dudf_workspace_bytes_query(cfg, m, 0). */
+int dudf_trace_rays(const dudf_net_cfg* cfg, const float* theta, const double* rays, double* t0, unsigned char* mask,
+                    unsigned char* hits, int64_t m, int inverse_mode, double alpha, double min_step,
+                    double surface_threshold, int max_iterations, int check_every, int* iterations_done,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* `grad_descent` (reference src/render_st.py:163-172): gd_steps times  t0[hits] -= normalize(grad f) * inverse(|f|). */
+int dudf_descend_rays(const dudf_net_cfg* cfg, const float* theta, double* t0, const unsigned char* hits, int64_t m,
+                      int inverse_mode, double alpha, double min_step, int gd_steps, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* The field part of `extract_fields` (reference src/render_mc.py:20-99) for grid points start .. start+count-1 of the
  * regular grid_n^3 grid on [-1,1]^3 (linear index, first axis slowest, coordinates derived from the index):
  * out_df (count) = inverse(gt_mode, |f|, alpha) with inverse_mode 0 'tanh' / 1 'siren' / 2 'squared'

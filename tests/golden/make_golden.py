@@ -135,6 +135,54 @@ def make_g6():
     np.savez_compressed(os.path.join(HERE, "g6_curvature.npz"), **out)
 
 
+def make_g7():
+    """G7: the sphere-tracing loop (reference src/render_st.py:136-172 `propagate_rays`, `grad_descent`; the module needs
+    open3d, so its numpy bookkeeping is re-issued here around the REFERENCE model, gradient() and inverse()): rays start
+    on the plane z = 0.95 and head into the domain."""
+    from src.util import normalize                                   # reference
+    out = {}
+    for tag, hid, pseed in (("tiny", [32, 32, 32], 11), ("full", [256] * 8, 123)):
+        P = synth.siren_params(hid, seed=pseed, dtype=np.float64)
+        model = ref_model(hid, P, torch.float32)
+        side = 24
+        gx, gy = np.meshgrid(np.linspace(-0.8, 0.8, side), np.linspace(-0.8, 0.8, side), indexing="ij")
+        t0 = np.stack([gx.ravel(), gy.ravel(), np.full(side * side, 0.95)], 1)
+        rays = np.stack([0.15 * gx.ravel(), -0.1 * gy.ravel(), -np.ones(side * side)], 1)
+        rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+        mask = np.ones(side * side, dtype=bool)
+        cfg = {"gt_mode": "tanh", "alpha": 100, "surface_threshold": 0.004, "max_iterations": 40, "gd_steps": 3}
+        out[f"{tag}_hidden"] = np.array(hid); out[f"{tag}_param_seed"] = pseed
+        out[f"{tag}_rays"] = rays.copy(); out[f"{tag}_t0"] = t0.copy()
+        for k in ("alpha", "surface_threshold", "max_iterations", "gd_steps"):
+            out[f"{tag}_{k}"] = cfg[k]
+
+        def query(pts, want_grad):
+            mo = model(torch.from_numpy(pts).float()[None])
+            y = mo["model_out"]
+            g = gradient(y, mo["model_in"])[0].detach().numpy() if want_grad else None
+            return y[0].detach().numpy(), g
+
+        hits = np.zeros_like(mask)
+        it = 0
+        while mask.sum() > 0 and it < cfg["max_iterations"]:
+            udfs, _ = query(t0[mask], False)
+            steps = inverse(cfg["gt_mode"], np.abs(udfs), cfg["alpha"])
+            t0[mask] += rays[mask] * steps
+            close = np.abs(steps).flatten() < cfg["surface_threshold"]
+            inside = np.logical_and(np.all(t0[mask] > -1, axis=1), np.all(t0[mask] < 1, axis=1))
+            hits[mask] += np.logical_and(close, inside)
+            mask[mask] *= np.logical_and(np.logical_not(close), inside)
+            it += 1
+        out[f"{tag}_hits"] = hits.copy(); out[f"{tag}_mask"] = mask.copy(); out[f"{tag}_t0_traced"] = t0.copy()
+        out[f"{tag}_iterations"] = it
+        for _ in range(cfg["gd_steps"]):
+            udfs, g = query(t0[hits], True)
+            steps = inverse(cfg["gt_mode"], np.abs(udfs), cfg["alpha"])
+            t0[hits] -= normalize(g) * steps
+        out[f"{tag}_t0_descended"] = t0.copy()
+    np.savez_compressed(os.path.join(HERE, "g7_rays.npz"), **out)
+
+
 def main():
     # ---- G1: tiny net, everything stored --------------------------------------------------
     out = {}
@@ -243,11 +291,14 @@ def main():
     out["batch0_x"] = batches[0][0]; out["batch0_sdf"] = batches[0][2]
     np.savez_compressed(os.path.join(HERE, "g5_beetle.npz"), **out)
     make_g6()
+    make_g7()
     print("golden fixtures written to", HERE)
 
 
 if __name__ == "__main__":
     if sys.argv[1:] == ["g6"]:
         make_g6()
+    elif sys.argv[1:] == ["g7"]:
+        make_g7()
     else:
         main()

@@ -291,3 +291,44 @@ def test_curvature_against_reference(golden_dir, tag):
     with pytest.raises(Exception):
         cfg5 = hip.make_cfg([512] * 2)
         hip.query_curvature(cfg5, torch.zeros(hip.theta_count(cfg5), device="cuda"), x)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_sphere_tracing_loop_against_reference(golden_dir, tag):
+    """§8(f) row 3: `propagate_rays` + `grad_descent` (reference src/render_st.py:136-172) with the reference signatures
+    and in-place numpy contract, marching on the GPU; against the same loop driven around the reference model
+    (tests/golden/g7_rays.npz).  Rays whose |step| sits within fp32 rounding of the threshold may retire an iteration
+    apart: >= 99 % of the rays must share their fate, and those sit within 2e-3 of the reference positions."""
+    from src.render_st import propagate_rays, grad_descent
+    from diffudf_amd import hip_ops as hip
+    G = np.load(os.path.join(golden_dir, "g7_rays.npz"))
+    model, P = make_model(list(G[f"{tag}_hidden"]), int(G[f"{tag}_param_seed"]))
+    rays, t0 = G[f"{tag}_rays"].copy(), G[f"{tag}_t0"].copy()
+    mask = np.ones(len(t0), dtype=bool)
+    net_cfg = {"gt_mode": "tanh", "alpha": float(G[f"{tag}_alpha"])}
+    rcfg = {"surface_threshold": float(G[f"{tag}_surface_threshold"]), "max_iterations": int(G[f"{tag}_max_iterations"]),
+            "gd_steps": int(G[f"{tag}_gd_steps"])}
+    hits = propagate_rays(model, rays, t0, mask, net_cfg, rcfg, "cuda:0")
+    assert hits.dtype == bool and mask.dtype == bool and t0.dtype == np.float64
+    same = (hits == G[f"{tag}_hits"]) & (mask == G[f"{tag}_mask"])
+    d = np.abs(t0 - G[f"{tag}_t0_traced"]).max(axis=1)
+    assert same.mean() >= 0.99, same.mean()
+    assert d[same].max() < 2e-3
+    # projection steps from the reference's own hit set and positions
+    t1 = G[f"{tag}_t0_traced"].copy()
+    grad_descent(model, t1, G[f"{tag}_hits"], net_cfg, rcfg, "cuda:0")
+    assert np.abs(t1 - G[f"{tag}_t0_descended"]).max() < 1e-4
+    untouched = ~G[f"{tag}_hits"]
+    assert np.array_equal(t1[untouched], G[f"{tag}_t0_traced"][untouched])
+    # the device loop stops early once every ray has retired, and a second call on retired rays is a no-op
+    d_rays = torch.from_numpy(rays).cuda(); d_t0 = torch.from_numpy(G[f"{tag}_t0"].copy()).cuda()
+    d_mask = torch.ones(len(t0), dtype=torch.uint8, device="cuda")
+    h2, iters = hip.trace_rays(model.hip_cfg, model.flat_parameters(), d_rays, d_t0, d_mask, "tanh", net_cfg["alpha"],
+                               rcfg["surface_threshold"], 400, check_every=4)
+    assert iters < 400 and int(d_mask.sum()) == 0
+    before = d_t0.clone()
+    h3, iters3 = hip.trace_rays(model.hip_cfg, model.flat_parameters(), d_rays, d_t0, d_mask, "tanh", net_cfg["alpha"],
+                                rcfg["surface_threshold"], 50, check_every=4)
+    assert iters3 == 4 and torch.equal(before, d_t0) and int(h3.sum()) == 0
+    with pytest.raises(ValueError):
+        propagate_rays(model, rays, G[f"{tag}_t0"].copy(), np.zeros(len(t0), dtype=bool), net_cfg, rcfg, "cuda:0")

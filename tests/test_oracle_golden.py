@@ -159,3 +159,30 @@ def test_curvature_oracle_against_reference(golden_dir, tag):
     # symmetric trilinear form: T is invariant under index permutations
     T = O.third_derivatives(P, x[:4])
     assert np.abs(T - np.transpose(T, (0, 2, 1, 3))).max() == 0 and np.abs(T - np.transpose(T, (0, 3, 2, 1))).max() == 0
+
+
+def _ray_agreement(hits_a, mask_a, t0_a, hits_b, mask_b, t0_b, thr):
+    """Fraction of rays with the same fate, and the largest position difference among those."""
+    same = (hits_a == hits_b) & (mask_a == mask_b)
+    d = np.abs(t0_a - t0_b).max(axis=1)
+    return same.mean(), d[same].max(), d[~same].max() if (~same).any() else 0.0
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_ray_marching_oracle_against_reference(golden_dir, tag):
+    """§8(f) row 3: the sphere-tracing loop (reference src/render_st.py:136-172) restated in oracle/rays_oracle.py against
+    the same loop driven around the reference model (tests/golden/g7_rays.npz)."""
+    from oracle import rays_oracle as R
+    G = np.load(os.path.join(golden_dir, "g7_rays.npz"))
+    P = synth.siren_params(list(G[f"{tag}_hidden"]), seed=int(G[f"{tag}_param_seed"]), dtype=np.float64)
+    rays, t0 = G[f"{tag}_rays"].copy(), G[f"{tag}_t0"].copy()
+    mask = np.ones(len(t0), dtype=bool)
+    thr = float(G[f"{tag}_surface_threshold"])
+    hits, it = R.propagate_rays(P, rays, t0, mask, "tanh", float(G[f"{tag}_alpha"]), thr, int(G[f"{tag}_max_iterations"]))
+    frac, dsame, ddiff = _ray_agreement(hits, mask, t0, G[f"{tag}_hits"], G[f"{tag}_mask"], G[f"{tag}_t0_traced"], thr)
+    assert it == int(G[f"{tag}_iterations"]) and frac >= 0.99, (it, frac)
+    assert dsame < 2e-3 and ddiff < 0.2          # rays with the same fate sit on the same point; stragglers are one step off
+    hits_ref = G[f"{tag}_hits"]
+    t1 = G[f"{tag}_t0_traced"].copy()
+    R.grad_descent(P, t1, hits_ref, "tanh", float(G[f"{tag}_alpha"]), int(G[f"{tag}_gd_steps"]))
+    assert np.abs(t1 - G[f"{tag}_t0_descended"]).max() < 1e-4
