@@ -67,7 +67,9 @@ int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
     int rc = 0;
     if (lo.ncol_h > 0) {
         a.tile0 = 0; a.ntiles = (int)(lo.ncol_h / DUDF_TILE_PTS); a.hess = 1;
-        if ((rc = dudf_launch_sweep(base + 4, lo.H, a, st))) return rc;
+        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base + 4, lo.H, lo.L)) rc = dudf_launch_sweep_bf16(base + 4, lo.H, a, st);
+        else rc = dudf_launch_sweep(base + 4, lo.H, a, st);
+        if (rc) return rc;
     }
     if (lo.ncol_n > 0) {
         a.tile0 = (int)(lo.ncol_h / DUDF_TILE_PTS); a.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); a.hess = 0;
@@ -104,7 +106,7 @@ int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, s
 int forward_common(Ctx& c, const float* theta, const float* x, int train, bool reverse) {
     int rc;
     if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
-    if (use_bf16_sweeps() && c.lo.ncol_n > 0 && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
+    if (use_bf16_sweeps() && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
     if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     // what the forward sweep has to leave behind: h_l only for training (weight gradients, r_l), cos if any later sweep

@@ -1,4 +1,4 @@
-// The four plain-column SIREN sweeps on the bf16 matrix cores at fp32 accuracy ("bf16x6", gfx950 / CDNA4).
+// The SIREN sweeps (plain columns and Hessian quads) on the bf16 matrix cores at fp32 accuracy ("bf16x6", gfx950 / CDNA4).
 //
 // Same sweeps, same tails, same stash as dudf_sweep.hip (see there for what each sweep computes and which reference
 // lines it replaces); what changes is how a hidden layer  OUT[feature][column] = M[feature][k] * IN[k][column]  is
@@ -99,28 +99,20 @@ __device__ __forceinline__ void dma_wait_b() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-// vector-memory operations of one step that are younger than its LDS-DMA: the operand loads of the next tail and
-// the stash stores of the current one (tests/test_isa_contract.py counts them in the built code object)
-template <int SW, int FL>
-constexpr int younger_b() {
-    return SW == SWEEP_FWD ? 2 + 2 * ((FL & 1) + ((FL >> 1) & 1))      // 2 bias loads + s/c stores of 2 tiles
-         : SW == SWEEP_REV ? ((FL & 1) ? 4 + 4 : 2)                     // c,s loads + q,r stores | c loads
-         : SW == SWEEP_ADJ_FWD ? 4 + 4                                  // c,r loads + A,e stores
-         : ((FL & 1) ? 4 + 2 : 2 + 2);                                  // SWEEP_ADJ_REV: c(,e) loads + zbar stores
-}
-
-struct TailOps { f32x4 o1a, o2a, o1b, o2b, ba, bb; };   // operands of one pair of tiles (+ bias, forward sweep)
+struct TailOps { f32x4 o1a, o2a, o3a, o1b, o2b, o3b, ba, bb; };   // operands of one pair of tiles (+ bias, forward sweeps)
 
 // One pass: the workgroup's waves 0..nact-1 take the 16-column groups g_first.. through a whole sweep.  Waves beyond
 // nact (the last, partial pass of a workgroup's share) only keep the weight stream and the barriers going.
 template <int H, int SW, int FL>
 __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
     using G = GeoB<H>;
-    static_assert(!is_hess(SW), "plain columns only");
+    static_assert(!is_jet(SW), "plain columns and Hessian quads");
     constexpr int BS = base_of(SW);
+    constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel, 0 = value, 1 + k = tangent d/dx_k
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
+    const bool isv = !HS || (lane & 3) == 0;           // value channel (always, on the plain path)
     const int nhid = a.L - 1;                          // hidden x hidden layers (>= 1 here)
     constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
 
@@ -139,9 +131,8 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     };
     const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 4);
     auto load_ops = [&](int layer, int kb, TailOps& o) {
-        f32x4 dummy;
-        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vo, o.o1a, o.o2a, dummy);
-        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vo, o.o1b, o.o2b, dummy);
+        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vo, o.o1a, o.o2a, o.o3a);
+        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vo, o.o1b, o.o2b, o.o3b);
         if constexpr (BS == SWEEP_FWD) {
             o.ba = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 32 * kb + 4 * q);
             o.bb = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 32 * kb + 16 + 4 * q);
@@ -150,17 +141,18 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // tail of tiles 2kb, 2kb+1 of `layer`: fp32 results (and the stash stores the sweep owes)
     auto run_tail = [&](int layer, int kb, const f32x4 z0, const f32x4 z1, const TailOps& o, f32x4& e0, f32x4& e1) {
         const f32x4 zero = {0, 0, 0, 0};
-        if constexpr (BS == SWEEP_FWD) {
-            e0 = epilogue<SW, FL>(a, z0 + o.ba, zero, zero, zero, stash_base(layer, 2 * kb), vo, true);
-            e1 = epilogue<SW, FL>(a, z1 + o.bb, zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, true);
+        if constexpr (BS == SWEEP_FWD) {             // z = W h + b only in the value channel
+            e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv);
+            e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv);
         } else {
-            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, zero, stash_base(layer, 2 * kb), vo, true);
-            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, zero, stash_base(layer, 2 * kb + 1), vo, true);
+            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv);
+            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv);
         }
     };
     auto pin_ops = [&](TailOps& o) {                    // make the compiler wait for these loads HERE
         if constexpr (BS == SWEEP_FWD) asm volatile("" : "+v"(o.ba), "+v"(o.bb));
         else asm volatile("" : "+v"(o.o1a), "+v"(o.o2a), "+v"(o.o1b), "+v"(o.o2b));
+        if constexpr (SW == SWEEP_ADJ_FWD_H || SW == SWEEP_ADJ_REV_H) asm volatile("" : "+v"(o.o3a), "+v"(o.o3b));
     };
 
     // chunk stream: chunk c = (matrix c / NKB, k-block c % NKB) lives in LDS buffer c % 3 and is fetched TWO steps
@@ -194,6 +186,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         if constexpr (BS == SWEEP_FWD) b = (q < 3) ? a.x4[p * 4 + q] : 0.f;           // bias is added by the tail
         if constexpr (BS == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;
         if constexpr (BS == SWEEP_ADJ_REV) yb = a.ybar[p];
+        if constexpr (SW == SWEEP_REV_H) yb = isv ? 1.f : 0.f;                         // adot_L^k = 0
 #pragma unroll
         for (int T = 0; T < G::NT; ++T) {
             if constexpr (kFwdDir) prev[T] = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
@@ -206,21 +199,25 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // MFMAs with B(c), interleaved with tail c+1 -> B(c+1) -> wait for chunk c+1 + barrier.  Tail t = pair t % NKB of
     // the layer feeding matrix t / NKB; the last step of a layer runs the first tail of the next one once its own
     // accumulators are final.
-    TailOps ops_cur, ops_n1;                           // pinned for the next tail / in flight for the one after
+    // Tail operands: plain columns keep two sets (the next tail's, pinned at the top of the step, and the one after it,
+    // loaded right behind the DMA: a full step ahead); the quad variants have a third operand array and no registers
+    // for that — one set, refilled right after the tail that consumed it (about 0.8 step ahead).
+    TailOps ops_cur, ops_n1;
     u32x4 bh, bm, bl;                                  // B operand of the current step
     f32x4 fin0 = {0, 0, 0, 0}, fin1 = {0, 0, 0, 0};    // fp32 results of pair 0 of the layer after the last matrix
     load_ops(in_layer(0), 0, ops_cur);
-    load_ops(in_layer(0), 1, ops_n1);
+    if constexpr (!HS) load_ops(in_layer(0), 1, ops_n1);
     {
         f32x4 e0, e1;
         run_tail(in_layer(0), 0, prev[0], prev[1], ops_cur, e0, e1);
         split8(e0, e1, bh, bm, bl);
+        if constexpr (HS) load_ops(in_layer(0), 1, ops_cur);
     }
 #pragma unroll
     for (int T = 0; T < G::NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
     dma_wait_b<0>();                                   // once per tile: chunks 0 and 1 and everything above
     __syncthreads();
-    constexpr int kYoung = younger_b<SW, FL>();
+    constexpr int kYoung = younger_ops<SW, FL>();
     for (int j = 0; j < nhid; ++j) {
         const int lin = in_layer(j), lnx = in_layer(j + 1);
 #pragma unroll
@@ -230,12 +227,15 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             auto frag = [&](int T, int pc) -> bf16x8 {
                 return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
             };
-            ops_cur = ops_n1;
+            if constexpr (!HS) ops_cur = ops_n1;
             pin_ops(ops_cur);
             const bool more = c + 2 < total;
             if (more) dma_issue<H>(chunk_src(c + 2), lds + ((gc + 2) % 3) * G::CHUNKB, lane, wave);
-            if (kb + 2 < G::NKB) load_ops(lin, kb + 2, ops_n1);      // operands of the tail after next: one full step ahead
-            else load_ops(lnx, kb + 2 - G::NKB, ops_n1);
+            auto load_after_next = [&](TailOps& o) {                 // operands of tail c+2
+                if (kb + 2 < G::NKB) load_ops(lin, kb + 2, o);
+                else load_ops(lnx, kb + 2 - G::NKB, o);
+            };
+            if constexpr (!HS) load_after_next(ops_n1);              // one full step ahead
             __builtin_amdgcn_sched_barrier(0);
             u32x4 nh, nm, nl;
             // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
@@ -262,11 +262,13 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                     f32x4 e0, e1;                                       // (spreading it over several tiles: no gain —
                     run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);   // the SIMD's other wave
                     split8(e0, e1, nh, nm, nl);                         //  covers the block)
+                    if constexpr (HS) load_after_next(ops_cur);
                 }
             }
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
                 run_tail(lnx, 0, acc[0], acc[1], ops_cur, fin0, fin1);
                 split8(fin0, fin1, nh, nm, nl);
+                if constexpr (HS) load_after_next(ops_cur);
 #pragma unroll
                 for (int T = 0; T < G::NT; ++T) { prev[T] = acc[T]; acc[T] = f32x4{0, 0, 0, 0}; }
             }
@@ -287,9 +289,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         for (int kb = 0; kb < G::NKB; ++kb) {
             f32x4 e0 = fin0, e1 = fin1;
             if (kb > 0) {
-                ops_cur = ops_n1;
-                if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_n1);
+                if constexpr (!HS) {
+                    ops_cur = ops_n1;
+                    if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_n1);
+                }
                 run_tail(lin, kb, prev[2 * kb], prev[2 * kb + 1], ops_cur, e0, e1);
+                if constexpr (HS) { if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_cur); }
             }
             if constexpr (BS == SWEEP_FWD) {
                 const f32x4 w0v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 4 * q);
@@ -308,7 +313,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         if constexpr (BS == SWEEP_FWD) {
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
-            part += a.theta[a.off_bo];
+            if (isv) part += a.theta[a.off_bo];         // tangent columns are derivatives: no constant term
             if (q == 0) a.y[p] = part;
         } else if constexpr (BS == SWEEP_REV) {
             if (q == 0) *reinterpret_cast<f32x4*>(a.g + p * 4) = f32x4{accg[0], accg[1], accg[2], 0.f};
@@ -394,6 +399,16 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         case SWEEP_ADJ_REV:
             if (a.have_e) DUDF_GO_B(SWEEP_ADJ_REV, 1); else DUDF_GO_B(SWEEP_ADJ_REV, 0);
             break;
+        // Hessian quads: same kernel, the tails couple the 4 lanes of a quad by DPP
+        case SWEEP_FWD_H:
+            if (!a.store_s) return DUDF_E_BADMODE;
+            DUDF_GO_B(SWEEP_FWD_H, 1);
+            break;
+        case SWEEP_REV_H:
+            if (a.train) DUDF_GO_B(SWEEP_REV_H, 1); else DUDF_GO_B(SWEEP_REV_H, 0);
+            break;
+        case SWEEP_ADJ_FWD_H: DUDF_GO_B(SWEEP_ADJ_FWD_H, 0); break;
+        case SWEEP_ADJ_REV_H: DUDF_GO_B(SWEEP_ADJ_REV_H, 0); break;
         default: return DUDF_E_UNSUPPORTED;
     }
 #undef DUDF_GO_B
@@ -403,7 +418,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
 }  // namespace
 
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
-    return H == 256 && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV;
+    return H == 256 && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV_H;
 }
 
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st) {
