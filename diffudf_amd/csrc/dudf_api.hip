@@ -140,7 +140,8 @@ int backward_common(Ctx& c, const float* theta, int have_g, float* dtheta, int a
 extern "C" {
 
 const char* dudf_version(void) {
-    return "dudf_hip 0.2 (gfx950, fp32 MFMA 16x16x4 sweeps incl. Hessian quads + 32x32x2 wgrad)";
+    return "dudf_hip 0.3 (gfx950: bf16x6 MFMA sweeps and weight-gradient GEMM at fp32 accuracy, f32-input MFMA variants, "
+           "Hessian quads, third-order jets, GPU sampler, ray marching)";
 }
 
 int64_t dudf_theta_count(const dudf_net_cfg* cfg) {

@@ -1,4 +1,6 @@
-// The four SIREN sweeps of the DiffUDF training hot path as ONE kernel template (gfx950 / CDNA4).
+// The SIREN sweeps of the DiffUDF training hot path on the f32-INPUT matrix instruction, as one kernel template
+// (gfx950 / CDNA4).  The headline configuration (256-wide layers) runs on the bf16x6 kernel, dudf_sweep_bf16.hip; this
+// one serves the other widths (32/64/128/512, with their Hessian quads), the third-order jets, and DUDF_SWEEP=f32.
 //
 //   SWEEP_FWD      value forward           z_l = W_l h_{l-1} + b_l, h_l = sin(w0 z_l), y          (reference src/model.py:131-135)
 //   SWEEP_REV      input gradient          a_{l-1} = W_l^T (w0 c_l a_l), df/dx = a_0             (src/diff_operators.py:208-212)
@@ -12,10 +14,10 @@
 //     elementwise sin/cos epilogue applied in registers — directly the B operand of layer l+1
 //     (B[k = lane>>4][j = lane&15], MFMA t of k-tile T consumes register t, i.e. k = 16T + 4*(lane>>4) + t,
 //     and the A operand takes the matching columns with one 16-byte LDS read).  Activations never touch LDS.
-//   * the 8 waves of a workgroup (128 points) walk the layers in lockstep and share the weights: every
-//     32-row chunk of W_l (or of the pre-transposed W_l^T for the reverse sweeps) is staged ONCE per
-//     workgroup global -> registers -> LDS (double buffered, one barrier per chunk) and read by all waves
-//     as A operands.  A chunk completes two 16-feature output tiles per wave over the full K, so the
+//   * the 4 waves of a workgroup (64 points; two workgroups per CU, one at H = 512) walk the layers in lockstep and
+//     share the weights: every 32-row chunk of W_l (or of the pre-transposed W_l^T for the reverse sweeps) is staged
+//     ONCE per workgroup into LDS (LDS-DMA for H = 256/512, through registers otherwise; double buffered, one barrier
+//     per chunk) and read by all waves as A operands.  A chunk completes two 16-feature output tiles per wave over the full K, so the
 //     sin/cos + stash epilogue of chunk r overlaps the MFMAs of chunk r+1.
 //   * what a later sweep needs (s_l, c_l, q_l, r_l/e_l, A_l, zbar_l) is stashed in HBM as one aligned
 //     16-byte store per lane and tile ([layer][feature/4][point][4]); the same arrays are the operands of
