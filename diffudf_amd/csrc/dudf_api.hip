@@ -67,8 +67,13 @@ int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
     int rc = 0;
     if (lo.ncol_h > 0) {
         a.tile0 = 0; a.ntiles = (int)(lo.ncol_h / DUDF_TILE_PTS); a.hess = 1;
-        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base + 4, lo.H, lo.L)) rc = dudf_launch_sweep_bf16(base + 4, lo.H, a, st);
-        else rc = dudf_launch_sweep(base + 4, lo.H, a, st);
+        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base + 4, lo.H, lo.L)) {
+            rc = dudf_launch_sweep_bf16(base + 4, lo.H, a, st);
+        } else {
+            SweepArgs b = a;
+            if (base == SWEEP_FWD) b.store_s = 1;                 // the f32 kernel's quad forward tail always keeps its outputs
+            rc = dudf_launch_sweep(base + 4, lo.H, b, st);
+        }
         if (rc) return rc;
     }
     if (lo.ncol_n > 0) {
@@ -112,7 +117,6 @@ int forward_common(Ctx& c, const float* theta, const float* x, int train, bool r
     // what the forward sweep has to leave behind: h_l only for training (weight gradients, r_l), cos if any later sweep
     // runs — a value-only query stores nothing, a value+gradient query half of what training does
     a.store_s = train ? 1 : 0; a.store_c = (reverse || train) ? 1 : 0; a.train = train;
-    if (c.lo.ncol_h > 0) a.store_s = 1;                       // the Hessian quads' forward tail always keeps its outputs
     if ((rc = run_sweep(SWEEP_FWD, c.lo, a, c.st))) return rc;
     if (reverse && (rc = run_sweep(SWEEP_REV, c.lo, a, c.st))) return rc;
     return 0;

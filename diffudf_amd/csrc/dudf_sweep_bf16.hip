@@ -401,8 +401,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
             break;
         // Hessian quads: same kernel, the tails couple the 4 lanes of a quad by DPP
         case SWEEP_FWD_H:
-            if (!a.store_s) return DUDF_E_BADMODE;
-            DUDF_GO_B(SWEEP_FWD_H, 1);
+            if (a.store_s) DUDF_GO_B(SWEEP_FWD_H, 1); else DUDF_GO_B(SWEEP_FWD_H, 0);   // queries do not need h | hdot again
             break;
         case SWEEP_REV_H:
             if (a.train) DUDF_GO_B(SWEEP_REV_H, 1); else DUDF_GO_B(SWEEP_REV_H, 0);
