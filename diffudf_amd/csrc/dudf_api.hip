@@ -253,7 +253,9 @@ int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const floa
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     a.x4 = c.ws + cl.o_x4; a.y = c.ws + cl.o_y; a.np = cl.npj; a.stash_layer = (int64_t)c.lo.H * cl.npj;
     a.tile0 = 0; a.ntiles = (int)(cl.npj / DUDF_TILE_PTS); a.hess = 1;
-    if ((rc = dudf_launch_sweep(SWEEP_FWD_J, c.lo.H, a, c.st))) return rc;
+    if (use_bf16_sweeps() && dudf_sweep_bf16_supported(SWEEP_FWD_J, c.lo.H, c.lo.L)) rc = dudf_launch_sweep_bf16(SWEEP_FWD_J, c.lo.H, a, c.st);
+    else rc = dudf_launch_sweep(SWEEP_FWD_J, c.lo.H, a, c.st);
+    if (rc) return rc;
     // 3. first-order eigenvector perturbation
     if ((rc = dudf_launch_curvature(c.ws + cl.o_y, lam, V, n, out_mean, out_gauss, out_shape, c.st))) return rc;
     hipError_t e = hipSuccess;

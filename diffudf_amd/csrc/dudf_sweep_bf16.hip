@@ -106,13 +106,13 @@ struct TailOps { f32x4 o1a, o2a, o3a, o1b, o2b, o3b, ba, bb; };   // operands of
 template <int H, int SW, int FL>
 __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
     using G = GeoB<H>;
-    static_assert(!is_jet(SW), "plain columns and Hessian quads");
     constexpr int BS = base_of(SW);
-    constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel, 0 = value, 1 + k = tangent d/dx_k
+    constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
+                                                       // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
-    const bool isv = !HS || (lane & 3) == 0;           // value channel (always, on the plain path)
+    const bool isv = !HS || (is_jet(SW) ? li == 0 : (lane & 3) == 0);   // value channel (always, on the plain path)
     const int nhid = a.L - 1;                          // hidden x hidden layers (>= 1 here)
     constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
 
@@ -408,6 +408,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
             break;
         case SWEEP_ADJ_FWD_H: DUDF_GO_B(SWEEP_ADJ_FWD_H, 0); break;
         case SWEEP_ADJ_REV_H: DUDF_GO_B(SWEEP_ADJ_REV_H, 0); break;
+        case SWEEP_FWD_J: DUDF_GO_B(SWEEP_FWD_J, 0); break;      // third-order Taylor jets (curvature query), nothing stashed
         default: return DUDF_E_UNSUPPORTED;
     }
 #undef DUDF_GO_B
@@ -417,7 +418,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
 }  // namespace
 
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
-    return H == 256 && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV_H;
+    return H == 256 && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
 }
 
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st) {

@@ -37,7 +37,7 @@ def test_bf16_sweep_wait_counts(tmp_path):
     emit_asm(os.path.join(REPO, "diffudf_amd", "csrc", "dudf_sweep_bf16.hip"), asm)
     res = analyse_bf16(asm)
     assert set(res) == {(0, 3), (0, 2), (0, 0), (1, 1), (1, 0), (2, 0), (3, 1), (3, 0),
-                        (4, 1), (4, 0), (5, 1), (5, 0), (6, 0), (7, 0)}           # + the Hessian-quad variants
+                        (4, 1), (4, 0), (5, 1), (5, 0), (6, 0), (7, 0), (8, 0)}           # + the Hessian-quad variants
     for key, v in res.items():
         assert v["scratch"] == 0, key
         for dma, ops, n in v["steps"]:
