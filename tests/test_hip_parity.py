@@ -51,7 +51,10 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-NETS = [([32, 32, 32], 63, 7), ([64] * 4, 200, 11), ([128] * 3, 130, 5), ([256] * 8, 1000, 123)]
+# [256, 256] and [256]*3: the shortest chunk streams the bf16x6 kernel sees (one / two hidden matrices), with column counts
+# that leave idle waves (17 columns) and a partial last pass (129)
+NETS = [([32, 32, 32], 63, 7), ([64] * 4, 200, 11), ([128] * 3, 130, 5), ([256] * 8, 1000, 123),
+        ([256, 256], 17, 3), ([256] * 3, 129, 4)]
 NETS_WIDE = NETS + [([512] * 3, 300, 9)]          # BASELINE configs[2]'s width (8x512 is exercised by bench.py --hidden 512)
 
 
