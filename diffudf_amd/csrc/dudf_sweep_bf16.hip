@@ -418,25 +418,35 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
 }  // namespace
 
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
-    return H == 256 && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
+    return (H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
 }
 
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st) {
     DudfProfScope prof(PROF_SWEEP_FWD + (which & 3), st);
     switch (H) {
         case 256: return launch_b<256>(which, a, st);
+        case 128: return launch_b<128>(which, a, st);
         default: return DUDF_E_UNSUPPORTED;
     }
 }
 
-int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
-    if (lo.H != 256 || lo.L < 2) return 0;
-    DudfProfScope prof(PROF_PACK, st);
-    using G = GeoB<256>;
+namespace {
+template <int H>
+int pack_b(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
+    using G = GeoB<H>;
     char* img_f = reinterpret_cast<char*>(ws + lo.ws_wimg);
     char* img_t = img_f + (size_t)(lo.L - 1) * G::IMGB;
     const int64_t total = (int64_t)2 * (lo.L - 1) * G::NKB * G::NT * 64;
-    hipLaunchKernelGGL(pack_bf16_kernel<256>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, theta, img_f, img_t,
+    hipLaunchKernelGGL(pack_bf16_kernel<H>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, theta, img_f, img_t,
                        lo.L - 1, lo.off_hid, lo.hid_stride);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
+    if (lo.L < 2) return 0;
+    DudfProfScope prof(PROF_PACK, st);
+    if (lo.H == 256) return pack_b<256>(lo, theta, ws, st);
+    if (lo.H == 128) return pack_b<128>(lo, theta, ws, st);
+    return 0;
 }
