@@ -1,4 +1,5 @@
-// The SIREN sweeps (plain columns and Hessian quads) on the bf16 matrix cores at fp32 accuracy ("bf16x6", gfx950 / CDNA4).
+// The SIREN sweeps (plain columns, Hessian quads, third-order jets; 256- and 128-wide layers) on the bf16 matrix cores at
+// fp32 accuracy ("bf16x6", gfx950 / CDNA4).
 //
 // Same sweeps, same tails, same stash as dudf_sweep.hip (see there for what each sweep computes and which reference
 // lines it replaces); what changes is how a hidden layer  OUT[feature][column] = M[feature][k] * IN[k][column]  is
@@ -26,8 +27,8 @@
 //     holding M[row m][the 8 features of k-slots (g, 0..7)].  The 48 KiB of a k-block (16 tiles x 3 pieces at H = 256)
 //     are contiguous, so LDS-DMA moves them verbatim in 1 KiB wave-instructions and the reads are lane-linear:
 //     conflict-free without padding or swizzle.  Three buffers (144 KiB), fetched two steps ahead, one barrier per
-//     k-block, hand-counted vmcnt as in the f32 kernel.  128 columns share every byte fetched from L2: at bf16 rates the f32 kernel's
-//     64-column workgroups would be bound by L2 -> LDS weight traffic, not by the matrix cores.
+//     k-block, hand-counted vmcnt as in the f32 kernel.  128 columns share every byte fetched from L2: at bf16 rates
+//     the f32 kernel's 64-column workgroups would be bound by L2 -> LDS weight traffic, not by the matrix cores.
 //   * the first layer (K = 3+1) and the output / df/dx matmuls stay on the fp32 MFMA.
 #include "dudf_sweep_common.h"
 
