@@ -53,7 +53,7 @@ struct LossArgs {
     const float* cot;                        // device, 4 floats
     const double* stats;                     // device, 3 doubles (s2)
     double* acc;                             // device, >= 4 doubles
-    int64_t n, n_h, ncol_h, np;
+    int64_t n, n_h, ncol_h, np, ncols;
     float w[4];
     float alpha, inv_n;                      // 1 / n_global
 };
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
         sd = sqrt((a.stats[2] - cnt * mu * mu) / (cnt - 1.0));
     }
     const int64_t nq = a.ncol_h / 4;                                   // quads (padded)
-    const int64_t units = nq + (a.np - a.ncol_h);
+    const int64_t units = nq + (a.ncols - a.ncol_h);
     for (int64_t uidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; uidx < units;
          uidx += (int64_t)gridDim.x * blockDim.x) {
         const bool quad = uidx < nq;
@@ -586,7 +586,7 @@ LossArgs make_loss_args(const DudfLayout& lo, const float* normals, const float*
     a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.normals = normals; a.sdf = sdf;
     a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar; a.cot = nullptr; a.stats = nullptr;
     a.acc = reinterpret_cast<double*>(ws + lo.ws_acc);
-    a.n = lo.n; a.n_h = lo.n_h; a.ncol_h = lo.ncol_h; a.np = lo.np;
+    a.n = lo.n; a.n_h = lo.n_h; a.ncol_h = lo.ncol_h; a.np = lo.np; a.ncols = lo.ncols;
     for (int i = 0; i < 4; ++i) a.w[i] = (float)w[i];
     a.alpha = (float)alpha; a.inv_n = (float)(1.0 / (double)n_global);
     return a;

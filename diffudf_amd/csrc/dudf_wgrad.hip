@@ -598,7 +598,7 @@ struct WgradSmallArgs {
     const float *Q, *A, *Z, *S;
     const float *x4, *gbar, *ybar;      // x4 [np][4]; gbar [np][4]; ybar [np]
     float* dtheta;
-    int64_t np, stash_layer, off_wo, off_bo;
+    int64_t np, ncols, stash_layer, off_wo, off_bo;
     int H, L, have_g;
     int pts_per_block;
 };
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int FQ = a.H / 4;
     const int64_t p0 = (int64_t)blockIdx.x * a.pts_per_block;
-    const int64_t p1 = (p0 + a.pts_per_block < a.np) ? p0 + a.pts_per_block : a.np;
+    const int64_t p1 = (p0 + a.pts_per_block < a.ncols) ? p0 + a.pts_per_block : a.ncols;
     const float* Q0 = a.Q;                                          // layer index 0
     const float* Z0 = a.Z;
     const float* AL = a.A + (int64_t)(a.L - 1) * a.stash_layer;
@@ -725,7 +725,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     WgradArgs a;
     a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S; a.ncol_h = lo.ncol_h;
     a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
-    a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.np / KT); a.L = lo.L;
+    a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.ncols / KT); a.L = lo.L;
     a.have_g = have_g; a.Hs = lo.H;
     int rc = 0;
     {
@@ -742,10 +742,10 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     if (rc) return rc;
     WgradSmallArgs s;
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
-    s.dtheta = dtheta; s.np = lo.np; s.stash_layer = lo.stash_layer;
+    s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
     s.pts_per_block = 1024;
-    const int grid = (int)((lo.np + s.pts_per_block - 1) / s.pts_per_block);
+    const int grid = (int)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block);
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
     const int gy = (lo.H / 4 >= 16) ? 4 : 1;
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid, gy), dim3(256), 0, st, s);
