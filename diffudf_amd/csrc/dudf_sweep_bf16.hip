@@ -79,20 +79,39 @@ __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf1
 __device__ __forceinline__ u32x4 as_u(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
 __device__ __forceinline__ f32x4 as_f(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
 
-// chunk r of a weight image -> LDS buffer, 1 KiB per wave-instruction (see dudf_sweep.hip for why this is inline asm)
+// One chunk of a weight image -> LDS buffer, 1 KiB per wave-instruction (see dudf_sweep.hip for why this is inline asm).
+// `lds_off` is the buffer's LDS byte offset, `voff` = lane * 16; this wave moves pieces wave*NDMA .. +NDMA-1.  One asm
+// block: scalar base + lane offset addressing, M0 (the LDS destination) saved and restored once — under 2 instructions
+// per piece instead of 11 through generic pointers.
 template <int H>
-__device__ __forceinline__ void dma_issue(const char* __restrict__ chunk, char* buf, int lane, int wave) {
+__device__ __forceinline__ void dma_issue(const char* __restrict__ chunk, unsigned lds_off, unsigned voff, int wave) {
     using G = GeoB<H>;
-#pragma unroll
-    for (int i = 0; i < G::NDMA; ++i) {
-        const int piece = wave * G::NDMA + i;
-        const char* g = chunk + (size_t)piece * G::FRAG + lane * 16;
-        const unsigned l = __builtin_amdgcn_readfirstlane(
-            (unsigned)(size_t)(__attribute__((address_space(3))) char*)(buf + piece * G::FRAG));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+    static_assert(G::NDMA == 6 || G::NDMA == 3, "asm below is written for 3 or 6 pieces per wave");
+    const uint64_t g0 = (uint64_t)(size_t)chunk + (uint64_t)wave * (G::NDMA * G::FRAG);       // wave-uniform
+    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
+    const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
+    const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_off + (unsigned)wave * (G::NDMA * G::FRAG));
+    unsigned keep;
+    if constexpr (G::NDMA == 6) {
+        // the instruction offset is added to the global AND to the LDS address; past its 4 KiB reach: a second lane
+        // offset and M0 + 4096
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %4, %2\n\t"
+                     "global_load_lds_dwordx4 %4, %2 offset:1024\n\t"
                      "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l0), "v"(voff + 4096u) : "memory", "scc");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l0) : "memory");
     }
 }
 template <int N>
@@ -165,14 +184,16 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         return image(j) + (size_t)(c - j * G::NKB) * G::CHUNKB;
     };
     __syncthreads();                                   // every wave is past its last LDS read of the previous tile
-    dma_issue<H>(chunk_src(0), lds + gc * G::CHUNKB, lane, wave);
-    dma_issue<H>(chunk_src(1), lds + ((gc + 1) % 3) * G::CHUNKB, lane, wave);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte offset of the buffers
+    const unsigned voff = (unsigned)lane * 16u;
+    dma_issue<H>(chunk_src(0), lds0 + gc * G::CHUNKB, voff, wave);
+    dma_issue<H>(chunk_src(1), lds0 + ((gc + 1) % 3) * G::CHUNKB, voff, wave);
     if (wave >= nact) {                                // same DMA pieces, same barriers, nothing else
         dma_wait_b<0>();
         __syncthreads();
         for (int c = 0; c < total; ++c) {
             const bool more = c + 2 < total;
-            if (more) dma_issue<H>(chunk_src(c + 2), lds + ((gc + 2) % 3) * G::CHUNKB, lane, wave);
+            if (more) dma_issue<H>(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB, voff, wave);
             gc = (gc + 1) % 3;
             if (more) dma_wait_b<G::NDMA>();           // only this step's pieces may still be in flight
             else dma_wait_b<0>();
@@ -231,7 +252,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             if constexpr (!HS) ops_cur = ops_n1;
             pin_ops(ops_cur);
             const bool more = c + 2 < total;
-            if (more) dma_issue<H>(chunk_src(c + 2), lds + ((gc + 2) % 3) * G::CHUNKB, lane, wave);
+            if (more) dma_issue<H>(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB, voff, wave);
             auto load_after_next = [&](TailOps& o) {                 // operands of tail c+2
                 if (kb + 2 < G::NKB) load_ops(lin, kb + 2, o);
                 else load_ops(lnx, kb + 2 - G::NKB, o);
