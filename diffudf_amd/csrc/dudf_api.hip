@@ -42,7 +42,7 @@ bool use_bf16_sweeps() {
 
 int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
     if (!ws || bytes < lo.total_bytes || (reinterpret_cast<uintptr_t>(ws) & 15)) return DUDF_E_WORKSPACE;
-    if (lo.np > (1ll << 26)) return DUDF_E_BADCFG;          // 32-bit lane offsets inside a stash layer
+    if (lo.np > (1ll << 25)) return DUDF_E_BADCFG;          // 32-bit lane BYTE offsets inside a stash layer (4 np granules of 16 B)
     return 0;
 }
 
@@ -215,7 +215,7 @@ int make_curv_layout(const dudf_net_cfg* cfg, int64_t n, CurvLayout* cl) {
     if (cl->q.H > 256) return DUDF_E_UNSUPPORTED;
     cl->npj = (16 * n + DUDF_TILE_PTS - 1) / DUDF_TILE_PTS * DUDF_TILE_PTS;
     if (cl->npj == 0) cl->npj = DUDF_TILE_PTS;
-    if (cl->npj > (1ll << 26)) return DUDF_E_BADCFG;
+    if (cl->npj > (1ll << 25)) return DUDF_E_BADCFG;
     int64_t o = (int64_t)(cl->q.total_bytes / sizeof(float));
     auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) / 4 * 4; return r; };
     cl->o_lam = take(3 * n); cl->o_V = take(9 * n); cl->o_x4 = take(4 * cl->npj); cl->o_y = take(cl->npj);

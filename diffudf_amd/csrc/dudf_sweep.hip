@@ -130,7 +130,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
         auto stash_base = [&](int layer, int T) -> int64_t {                   // wave-uniform
             return (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
         };
-        const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 4);           // this lane's granule
+        const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);          // this lane's granule, in bytes
 
         // every wave of the workgroup is past its last LDS read of the previous tile before buffers are refilled
         __syncthreads();

@@ -146,10 +146,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     auto bias_ptr = [&](int layer) -> const float* {   // forward sweep: b_{layer+1}
         return layer == 0 ? a.theta + 3 * H : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;
     };
-    auto stash_base = [&](int layer, int T) -> int64_t {
-        return (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
+    auto stash_base = [&](int layer, int T) -> int64_t {              // wave-uniform, and told so: SGPR base + lane offset
+        const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
     };
-    const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 4);
+    const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);     // this lane's granule, in bytes
     auto load_ops = [&](int layer, int kb, TailOps& o) {
         epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vo, o.o1a, o.o2a, o.o3a);
         epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vo, o.o1b, o.o2b, o.o3b);

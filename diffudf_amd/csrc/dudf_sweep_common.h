@@ -44,8 +44,10 @@ __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2&
 // Stash addressing: `ub` is a WAVE-UNIFORM float offset (layer and tile folded in, lives in SGPRs),
 // `vo` the lane's 32-bit float offset ((quarter*np + point)*4): global_load/store take the saddr form
 // and no per-tile 64-bit address is kept in VGPRs.
-#define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>((arr) + (ub) + (vo))
-#define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>((arr) + (ub) + (vo))
+// (`vo` in BYTES: "uniform base + zero-extended 32-bit lane offset" is what hipcc turns into the scalar-base addressing
+//  mode; with a float offset it builds a 64-bit address per lane and access instead)
+#define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>(reinterpret_cast<char*>((arr) + (ub)) + (vo))
+#define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>((arr) + (ub)) + (vo))
 // the stash is a stream (written once, read once or twice, 14 GB per step): non-temporal accesses
 #define DUDF_ST(arr, ub, vo, val) __builtin_nontemporal_store((f32x4)(val), DUDF_AT(arr, ub, vo))
 #define DUDF_LD(arr, ub, vo) __builtin_nontemporal_load(DUDF_CAT(arr, ub, vo))
