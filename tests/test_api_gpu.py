@@ -332,3 +332,18 @@ def test_sphere_tracing_loop_against_reference(golden_dir, tag):
     assert iters3 == 4 and torch.equal(before, d_t0) and int(h3.sum()) == 0
     with pytest.raises(ValueError):
         propagate_rays(model, rays, G[f"{tag}_t0"].copy(), np.zeros(len(t0), dtype=bool), net_cfg, rcfg, "cuda:0")
+
+
+def test_empty_inputs_are_no_ops():
+    """Edge cases of the query entry points added this round: zero rays / zero points."""
+    from diffudf_amd import hip_ops as hip
+    model, _ = make_model([256] * 3, 5)
+    cfg, th = model.hip_cfg, model.flat_parameters()
+    z3 = torch.zeros(0, 3, dtype=torch.float64, device="cuda")
+    hits, iters = hip.trace_rays(cfg, th, z3, z3.clone(), torch.zeros(0, dtype=torch.uint8, device="cuda"), "tanh", 100, 0.004, 10)
+    assert hits.numel() == 0 and iters == 0
+    hip.descend_rays(cfg, th, z3.clone(), torch.zeros(0, dtype=torch.uint8, device="cuda"), "tanh", 100, 2)
+    lam, V, mean, gauss, J = hip.query_curvature(cfg, th, torch.zeros(0, 3, device="cuda"), want_shape=True)
+    assert lam.shape == (0, 3) and V.shape == (0, 3, 3) and mean.numel() == 0 and J.shape == (0, 3, 3)
+    f, g = hip.query(cfg, th, torch.zeros(0, 3, device="cuda"))
+    assert f.numel() == 0 and g.shape == (0, 3)
