@@ -329,17 +329,22 @@ __global__ __launch_bounds__(256) void make_x4_kernel(const float* __restrict__ 
 }
 
 // ---- Adam (torch.optim.Adam single-tensor semantics, reference train.py:334-337) -------------------
+// Operation by operation what torch's CUDA Adam executes (torch/optim/adam.py _multi_tensor_adam: lerp_, mul_, addcmul_,
+// sqrt, div_, add_, addcdiv_), with the SAME constants: 1 - beta are formed in double on the host and rounded once
+// (1.f - 0.999f in float is off by 1.3e-5 relative, which moved the second moment and, over a dozen steps, the loss
+// curve by 1e-5).  Each torch kernel rounds its result to fp32; inside one kernel clang contracts a*b + c, as it does here.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float b1, float b2, float eps, float step_size, float bc2_sqrt,
-                                                   float gscale) {
+                                                   float w1, float b2, float w2, float eps, float step_size,
+                                                   float bc2_sqrt, float gscale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // lerp, as torch does
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        const float mi = fmaf(w1, gi - m[i], m[i]);               // lerp_(grad, 1 - beta1), weight < 0.5 branch
+        const float vs = __fmul_rn(v[i], b2);                      // mul_(beta2)
+        const float vi = fmaf(__fmul_rn(w2, gi), gi, vs);          // addcmul_(grad, grad, value = 1 - beta2)
         m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        theta[i] = theta[i] - step_size * (mi / denom);
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+        theta[i] = fmaf(-step_size, __fdiv_rn(mi, denom), theta[i]);   // addcdiv_(exp_avg, denom, value = -step_size)
     }
 }
 
@@ -650,8 +655,8 @@ int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n
                      double eps, int64_t step, double gscale, hipStream_t st) {
     DudfProfScope prof(PROF_ADAM, st);
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, theta, g, m, v, n, (float)b1, (float)b2,
-                       (float)eps, (float)(lr / bc1), (float)sqrt(bc2), (float)gscale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, theta, g, m, v, n, (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2), (float)gscale);
     return (int)hipGetLastError();
 }
 

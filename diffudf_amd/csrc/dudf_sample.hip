@@ -45,44 +45,46 @@ struct SampleArgs {
     uint64_t k_on, k_fx, k_fy, k_fz, k_pick, k_n1, k_n2;
 };
 
-// squared distance from p to triangle (a,b,c): closest point by Voronoi regions of the triangle
-__device__ __forceinline__ float tri_dist2(float px, float py, float pz, const float* t) {
-    const float ax = t[0], ay = t[1], az = t[2];
-    const float abx = t[3] - ax, aby = t[4] - ay, abz = t[5] - az;
-    const float acx = t[6] - ax, acy = t[7] - ay, acz = t[8] - az;
-    const float apx = px - ax, apy = py - ay, apz = pz - az;
-    const float d1 = abx * apx + aby * apy + abz * apz;
-    const float d2 = acx * apx + acy * apy + acz * apz;
-    float cx, cy, cz;                                  // closest point - a
-    if (d1 <= 0.f && d2 <= 0.f) { cx = cy = cz = 0.f; }
+// squared distance from p to triangle (a,b,c): closest point by Voronoi regions of the triangle.  In fp64, like the
+// oracle (and like nothing in fp32 can be: |p - c|^2 of coordinates ~1 carries 1e-7 absolute, 1e-4 of a near-surface
+// distance of 1e-3); 2 k triangles x 2 k queries per step is noise for the fp64 vector pipe.
+__device__ __forceinline__ double tri_dist2(double px, double py, double pz, const float* t) {
+    const double ax = t[0], ay = t[1], az = t[2];
+    const double abx = t[3] - ax, aby = t[4] - ay, abz = t[5] - az;
+    const double acx = t[6] - ax, acy = t[7] - ay, acz = t[8] - az;
+    const double apx = px - ax, apy = py - ay, apz = pz - az;
+    const double d1 = abx * apx + aby * apy + abz * apz;
+    const double d2 = acx * apx + acy * apy + acz * apz;
+    double cx, cy, cz;                                  // closest point - a
+    if (d1 <= 0.0 && d2 <= 0.0) { cx = cy = cz = 0.0; }
     else {
-        const float bpx = apx - abx, bpy = apy - aby, bpz = apz - abz;
-        const float d3 = abx * bpx + aby * bpy + abz * bpz;
-        const float d4 = acx * bpx + acy * bpy + acz * bpz;
-        if (d3 >= 0.f && d4 <= d3) { cx = abx; cy = aby; cz = abz; }
+        const double bpx = apx - abx, bpy = apy - aby, bpz = apz - abz;
+        const double d3 = abx * bpx + aby * bpy + abz * bpz;
+        const double d4 = acx * bpx + acy * bpy + acz * bpz;
+        if (d3 >= 0.0 && d4 <= d3) { cx = abx; cy = aby; cz = abz; }
         else {
-            const float vc = d1 * d4 - d3 * d2;
-            if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
-                const float v = d1 / (d1 - d3);
+            const double vc = d1 * d4 - d3 * d2;
+            if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+                const double v = d1 / (d1 - d3);
                 cx = v * abx; cy = v * aby; cz = v * abz;
             } else {
-                const float cpx = apx - acx, cpy = apy - acy, cpz = apz - acz;
-                const float d5 = abx * cpx + aby * cpy + abz * cpz;
-                const float d6 = acx * cpx + acy * cpy + acz * cpz;
-                if (d6 >= 0.f && d5 <= d6) { cx = acx; cy = acy; cz = acz; }
+                const double cpx = apx - acx, cpy = apy - acy, cpz = apz - acz;
+                const double d5 = abx * cpx + aby * cpy + abz * cpz;
+                const double d6 = acx * cpx + acy * cpy + acz * cpz;
+                if (d6 >= 0.0 && d5 <= d6) { cx = acx; cy = acy; cz = acz; }
                 else {
-                    const float vb = d5 * d2 - d1 * d6;
-                    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
-                        const float w = d2 / (d2 - d6);
+                    const double vb = d5 * d2 - d1 * d6;
+                    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+                        const double w = d2 / (d2 - d6);
                         cx = w * acx; cy = w * acy; cz = w * acz;
                     } else {
-                        const float va = d3 * d6 - d5 * d4;
-                        if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
-                            const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+                        const double va = d3 * d6 - d5 * d4;
+                        if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+                            const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
                             cx = abx + w * (acx - abx); cy = aby + w * (acy - aby); cz = abz + w * (acz - abz);
                         } else {
-                            const float den = 1.f / (va + vb + vc);
-                            const float v = vb * den, w = vc * den;
+                            const double den = 1.0 / (va + vb + vc);
+                            const double v = vb * den, w = vc * den;
                             cx = abx * v + acx * w; cy = aby * v + acy * w; cz = abz * v + acz * w;
                         }
                     }
@@ -90,7 +92,7 @@ __device__ __forceinline__ float tri_dist2(float px, float py, float pz, const f
             }
         }
     }
-    const float dx = apx - cx, dy = apy - cy, dz = apz - cz;
+    const double dx = apx - cx, dy = apy - cy, dz = apz - cz;
     return dx * dx + dy * dy + dz * dz;
 }
 
@@ -130,14 +132,14 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
             known = fabsf(off);
         }
     }
-    float best = 3.0e38f;
+    double best = 3.0e38;
     for (int64_t t0 = 0; t0 < a.n_tri; t0 += TRI_TILE) {
         const int cnt = (int)((a.n_tri - t0 < TRI_TILE) ? a.n_tri - t0 : TRI_TILE);
         __syncthreads();
         for (int e = threadIdx.x; e < cnt * 9; e += blockDim.x) tl[e] = a.tri[t0 * 9 + e];
         __syncthreads();
         if (query)
-            for (int t = 0; t < cnt; ++t) best = fminf(best, tri_dist2(px, py, pz, tl + t * 9));
+            for (int t = 0; t < cnt; ++t) best = fmin(best, tri_dist2((double)px, (double)py, (double)pz, tl + t * 9));
     }
     if (cloud_only)
         for (int64_t t0 = 0; t0 < a.n_pc; t0 += TRI_TILE * 3) {         // the same LDS tile holds 768 cloud points
@@ -147,14 +149,14 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
             __syncthreads();
             if (query)
                 for (int t = 0; t < cnt; ++t) {
-                    const float dx = px - tl[t * 3], dy = py - tl[t * 3 + 1], dz = pz - tl[t * 3 + 2];
-                    best = fminf(best, dx * dx + dy * dy + dz * dz);
+                    const double dx = (double)px - tl[t * 3], dy = (double)py - tl[t * 3 + 1], dz = (double)pz - tl[t * 3 + 2];
+                    best = fmin(best, dx * dx + dy * dy + dz * dz);
                 }
         }
     if (live) {
         a.x[i * 3] = px; a.x[i * 3 + 1] = py; a.x[i * 3 + 2] = pz;
         a.normals[i * 3] = nx; a.normals[i * 3 + 1] = ny; a.normals[i * 3 + 2] = nz;
-        a.sdf[i] = query ? sqrtf(best) : known;
+        a.sdf[i] = query ? (float)sqrt(best) : known;
     }
 }
 

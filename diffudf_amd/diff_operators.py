@@ -14,9 +14,15 @@ from ._lib import DudfError
 
 
 def _source(y, x):
+    """(model, coords) behind a reference-style (y, x) pair.  `y` carries the tag when it is exactly what `forward`
+    returned; any tensor DERIVED from it (the reference's own `pred_sdf.squeeze(-1)`, src/loss_functions.py:141, a
+    reshape, a slice of all points) has lost Python attributes, so the lookup falls back to `x`: `forward` registers
+    the 'model_in' tensor it hands out.  What stays unsupported: an `x` that is not the 'model_in' object itself."""
     src = getattr(y, "_dudf_src", None)
+    if src is None and getattr(x, "_dudf_model", None) is not None:
+        src = (x._dudf_model, x)
     if src is None:
-        raise DudfError("gradient/hessian: `y` was not produced by diffudf_amd.model.SIREN.forward "
+        raise DudfError("gradient/hessian: neither `y` nor `x` comes from diffudf_amd.model.SIREN.forward "
                         "(generic autograd graphs have no HIP path here)")
     model, coords = src[0](), src[1]
     if model is None:
@@ -26,14 +32,31 @@ def _source(y, x):
     return model, coords
 
 
+def _kind(y, coords):
+    """What field of the network `y` is: tagged results keep their tag; an untagged tensor with one value per point
+    is the model output (or a view of it)."""
+    k = getattr(y, "_dudf_kind", None)
+    if k is not None:
+        return k
+    n = coords.numel() // 3
+    if y.numel() == n:
+        return "value"
+    raise DudfError("this tensor is not a field the HIP path knows (model output, its gradient, or the eigen-normal "
+                    "field of compute_normals_and_cd); slices of a gradient have no HIP path — use hessian(y, x)")
+
+
 def gradient(y, x, grad_outputs=None):
     """dy/dx, shaped like x — reference src/diff_operators.py:208-212."""
     model, coords = _source(y, x)
+    if _kind(y, coords) != "value":
+        raise DudfError("gradient(y, x): `y` must be the model output; for second derivatives use hessian / laplace")
     x2 = coords.detach().reshape(-1, 3)
     _, g = hip_ops.query(model.hip_cfg, model.flat_parameters(), x2, want_grad=True)
     g = g.reshape(coords.shape)
     if grad_outputs is not None:
         g = g * grad_outputs.reshape(coords.shape[:-1] + (1,))
+    else:
+        g._dudf_kind = "grad"                          # divergence(gradient(y, x), x) finds its way (laplace)
     return g
 
 
@@ -47,7 +70,19 @@ def hessian(y, x):
 
 
 def divergence(y, x):
-    raise DudfError("divergence of an arbitrary vector field has no HIP path; for the field's own gradient use laplace")
+    """sum_i d y_i / d x_i, (1,N,1) — reference src/diff_operators.py:201-205, for the two vector fields this path
+    produces: the gradient of the model output (trace of the Hessian) and the eigen-normal field of
+    `render_st.compute_normals_and_cd` (trace of the shape operator the curvature kernel returns)."""
+    model, coords = _source(y, x)
+    kind = _kind(y, coords)
+    x2 = coords.detach().reshape(-1, 3)
+    if kind == "grad":
+        _, _, h = hip_ops.query_hessian(model.hip_cfg, model.flat_parameters(), x2)
+    elif kind == "eig_normal":
+        _, _, _, _, h = hip_ops.query_curvature(model.hip_cfg, model.flat_parameters(), x2, want_shape=True)
+    else:
+        raise DudfError("divergence: only gradient(y, x) and compute_normals_and_cd's normals have a HIP path")
+    return (h[:, 0, 0] + h[:, 1, 1] + h[:, 2, 2]).reshape(coords.shape[:-1] + (1,))
 
 
 def laplace(y, x):

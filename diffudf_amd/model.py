@@ -171,4 +171,6 @@ class SIREN(nn.Module):
         y = _SirenValue.apply(self, coords_org, *self.parameters())
         # lets diff_operators.gradient(y, x) find the network that produced y
         y._dudf_src = (weakref.ref(self), coords_org)
+        # ... and anything DERIVED from y (squeeze, reshape: Python attributes do not survive) through model_in
+        coords_org._dudf_model = weakref.ref(self)          # (no self-reference: no cycle)
         return {"model_in": coords_org, "model_out": y}

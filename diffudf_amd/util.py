@@ -25,8 +25,11 @@ def load_experiment_parameters(parameters_path):
         return {}
 
 
-def normalize(v):
+def normalize(arr):
+    """Reference src/util.py:34-39: a 1-D array is divided by its norm, a 2-D (M,3) array ROW BY ROW (a zero vector
+    or row gives nan/inf exactly like the reference's plain division)."""
     import numpy as np
-    v = np.asarray(v, dtype=float)
-    n = np.linalg.norm(v)
-    return v if n == 0 else v / n
+    arr = np.asarray(arr)
+    if arr.ndim == 1:
+        return arr / np.linalg.norm(arr)
+    return arr / np.linalg.norm(arr, axis=1, keepdims=True)

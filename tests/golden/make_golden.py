@@ -183,6 +183,28 @@ def make_g7():
     np.savez_compressed(os.path.join(HERE, "g7_rays.npz"), **out)
 
 
+def make_g8():
+    """G8: small operator fixtures — reference src/util.py:34-39 `normalize` (1-D and per-row 2-D), reference
+    src/diff_operators.py:196-205 `laplace` / `divergence` of the model's own gradient field."""
+    from src.util import normalize                                   # reference
+    from src.diff_operators import laplace, divergence               # reference
+    out = {}
+    v = synth.uniform01(5, 801, 0, 21).reshape(7, 3) * 4.0 - 2.0
+    out["norm_in_2d"] = v; out["norm_out_2d"] = normalize(v)
+    out["norm_in_1d"] = v[2].copy(); out["norm_out_1d"] = normalize(v[2].copy())
+    for tag, hid, pseed, n in (("tiny", [32, 32, 32], 11, 48), ("full", [256] * 8, 123, 40)):
+        P = synth.siren_params(hid, seed=pseed, dtype=np.float64)
+        x64 = synth.uniform01(77, 601, 0, 3 * n).reshape(n, 3) * 1.6 - 0.8        # the points of G6
+        model = ref_model(hid, P, torch.float64)
+        x = torch.from_numpy(x64.astype(np.float32).astype(np.float64))[None]
+        mo = model(x)
+        lap = laplace(mo["model_out"], mo["model_in"])
+        g = gradient(mo["model_out"], mo["model_in"])
+        div = divergence(g, mo["model_in"])
+        out[f"{tag}_laplace"] = lap.detach().numpy()[0]; out[f"{tag}_div_grad"] = div.detach().numpy()[0]
+    np.savez_compressed(os.path.join(HERE, "g8_operators.npz"), **out)
+
+
 def main():
     # ---- G1: tiny net, everything stored --------------------------------------------------
     out = {}
@@ -292,6 +314,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g5_beetle.npz"), **out)
     make_g6()
     make_g7()
+    make_g8()
     print("golden fixtures written to", HERE)
 
 
@@ -300,5 +323,7 @@ if __name__ == "__main__":
         make_g6()
     elif sys.argv[1:] == ["g7"]:
         make_g7()
+    elif sys.argv[1:] == ["g8"]:
+        make_g8()
     else:
         main()

@@ -1,0 +1,71 @@
+# coding: utf-8
+"""Child process of tests/test_multirank_gpu.py (not a test file): ONE rank of a world that shares cuda:0 over gloo
+(DUDF_TEST_SHARE_GPU=1; RCCL refuses two ranks on one device).  Runs the real HIP TrainEngine on this rank's stratified
+shard of one global batch and writes what rank 0 ends up with.
+
+    python tests/multirank_worker.py engine <case> <out.npz>        RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the env
+    python tests/multirank_worker.py train  <cfg.json> <unused>     train.py's own loop (distributed when WORLD_SIZE > 1)
+"""
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HIDDEN = [256] * 8
+N_GLOBAL = 6000
+STEPS = 3
+CASES = {"s1eik": (0, [1e4, 1e4, 0.0, 1e3], 1e-4), "s1full": (0, [1e4, 1e4, 1e4, 1e3], 1e-4), "s2": (1, [1e5, 1e5], 1e-6)}
+
+
+def run_engine(case, out):
+    from diffudf_amd import synth
+    from diffudf_amd.engine import TrainEngine
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(0)
+    if world > 1:
+        torch.distributed.init_process_group("gloo")
+    mode, w, lr = CASES[case]
+    dev = torch.device("cuda", 0)
+    theta = torch.from_numpy(synth.flatten_params(synth.siren_params(HIDDEN, seed=123))).to(dev)
+    eng = TrainEngine(HIDDEN, theta)
+    assert eng.world == world
+    hist, first_grad = [], None
+    for t in range(STEPS):
+        idx = synth.stratified_shard(N_GLOBAL, rank, world)
+        parts = np.split(idx, np.flatnonzero(np.diff(idx) != 1) + 1)
+        b = [synth.training_batch(N_GLOBAL, seed=5, step=t, lo=int(p[0]), hi=int(p[-1]) + 1) for p in parts]
+        x, nrm, sdf = [torch.from_numpy(np.concatenate([q[k] for q in b])).to(dev) for k in range(3)]
+        sdf = sdf.reshape(-1)
+        n_hess = int((sdf == 0).sum()) if case == "s1full" else 0
+        terms = eng.loss_and_grad(mode, x, nrm, sdf, w, 100.0, n_global=N_GLOBAL, n_hess=n_hess)
+        if t == 0:
+            first_grad = eng.dtheta.cpu().numpy().copy()
+        eng.adam(lr)
+        hist.append(terms.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out, hist=np.array(hist), dtheta0=first_grad, theta=theta.cpu().numpy())
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def run_train(cfg_path):
+    import train
+    cfg = json.load(open(cfg_path))
+    train.setup_train(cfg, 0)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "engine":
+        run_engine(sys.argv[2], sys.argv[3])
+    else:
+        run_train(sys.argv[2])

@@ -28,8 +28,9 @@ def test_gpu_sampler_matches_oracle(golden_dir):
     assert ds.n_global == 2997 and ds.samplesOnSurface == 999
     x, nrm, sdf = ds.sample(0)
     # the batch the reference trajectory was generated on
-    assert np.abs(x.cpu().numpy() - G["batch0_x"]).max() < 1e-6
-    assert np.abs(sdf.cpu().numpy() - G["batch0_sdf"][:, 0]).max() < 2e-6
+    # (coordinates within one fp32 ulp at |x| < 1; distances to 2 ulp of 1.0 — the oracle measures them in fp64)
+    assert np.abs(x.cpu().numpy() - G["batch0_x"]).max() <= 1.2e-7
+    assert np.abs(sdf.cpu().numpy() - G["batch0_sdf"][:, 0]).max() <= 2.4e-7
     assert (sdf[:999] == 0).all() and (sdf[999:] > 0).all() and (nrm[999:] == 0).all()
     # sharded: rank 1 of 3 produces exactly its slices, at a later step
     ds3 = PointCloud(BEETLE, bs, [0.333, 0.666], 1, device="cuda:0", seed=7, rank=1, world=3)
@@ -71,61 +72,107 @@ def test_gpu_sampler_point_cloud_only():
     assert torch.equal(got, sdf)
 
 
-@pytest.mark.parametrize("name,w", [("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])])
-def test_beetle_training_follows_reference(golden_dir, name, w):
-    """Loss after N steps on the beetle mesh within 1e-4 (relative) of the reference (north star); with the
-    eigenvector term on, the bar is the reference's own fp32-vs-fp64 drift (it is chaotic)."""
-    from src.dataset import PointCloud
-    from src.loss_functions import loss_s1
+def _fresh_model(G):
     from src.model import SIREN
-    G = np.load(os.path.join(golden_dir, "g5_beetle.npz"))
     hidden = list(G["hidden"])
     model = SIREN(3, 1, hidden, w0=30)
     sd = {}
     for i, (wt, b) in enumerate(synth.siren_params(hidden, seed=int(G["param_seed"]))):
         sd[f"net.{i}.0.weight"] = torch.from_numpy(wt); sd[f"net.{i}.0.bias"] = torch.from_numpy(b)
     model.load_state_dict(sd)
-    model.to("cuda:0")
-    ds = PointCloud(BEETLE, int(G["batch_size"]), [0.333, 0.666], 1, device="cuda:0", seed=int(G["batch_seed"]))
+    return model.to("cuda:0")
+
+
+def _fixture_batches(G):
+    """The EXACT batches the reference trajectory of g5_beetle.npz was run on: regenerated on the host with the
+    sampler oracle, as tests/golden/make_golden.py does (batch 0 is stored in the fixture and compared bit for bit)."""
+    from diffudf_amd import mesh
+    tri, pos, nrm = mesh.prepare(BEETLE, int(G["surface_points"]), seed=int(G["batch_seed"]))
+    bs = int(G["batch_size"])
+    n_on, n_off = int(bs * 0.333), int(bs * 0.666)
+    out = [SO.sample_batch(tri, pos, nrm, n_on, n_off // 2, n_off - n_off // 2, seed=int(G["batch_seed"]), step=t)
+           for t in range(int(G["steps"]))]
+    assert np.array_equal(out[0][0], G["batch0_x"]) and np.array_equal(out[0][2], G["batch0_sdf"])
+    return out
+
+
+@pytest.mark.parametrize("source", ["fixture_batches", "hip_sampler"])
+@pytest.mark.parametrize("name,w", [("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])])
+def test_beetle_training_follows_reference(golden_dir, name, w, source):
+    """North star: loss within 1e-4 (relative) of the reference after N steps on the beetle mesh.  The reference's own
+    loop (loss dict -> sum -> backward -> torch.optim.Adam, train.py:195-222) is run (a) on the fixture's exact
+    batches and (b) on the batches of the HIP sampler (equal to them within one fp32 ulp of the coordinates).
+    Eikonal loss: every one of the 12 steps within 1e-4 of the reference's fp64 curve (measured on MI355X: <= 7e-7;
+    the reference's own fp32 run is within 2e-7).  With the eigenvector term on, the reference's fp32 run leaves its own
+    fp64 run by 1.7e-3 at step 2 and 0.36 later (chaotic: 1/(lambda_2 - lambda_j) factors), so the bar there is that
+    drift, see DESIGN.md §4."""
+    from src.dataset import PointCloud
+    from src.loss_functions import loss_s1
+    G = np.load(os.path.join(golden_dir, "g5_beetle.npz"))
+    hidden = list(G["hidden"])
+    model = _fresh_model(G)
+    steps = int(G["steps"])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")  # noqa: E731
+    if source == "fixture_batches":
+        batches = [(d(x)[None], d(n)[None], d(s)[None]) for x, n, s in _fixture_batches(G)]
+    else:
+        ds = PointCloud(BEETLE, int(G["batch_size"]), [0.333, 0.666], 1, device="cuda:0", seed=int(G["batch_seed"]))
+        batches = [next(iter(ds)) for _ in range(steps)]
     opt = torch.optim.Adam(lr=1e-4, params=model.parameters())
     hist = []
-    for t in range(int(G["steps"])):
-        for x, nrm, sdf in iter(ds):
-            opt.zero_grad()
-            loss = loss_s1(model, x, {"normals": nrm, "sdf": sdf}, w, 100)
-            total = torch.zeros((1, 1), device="cuda:0")
-            for l in loss.values():
-                total += l
-            total.backward()
-            opt.step()
-            hist.append([l.item() for l in loss.values()])
+    for x, nrm, sdf in batches:
+        opt.zero_grad()
+        loss = loss_s1(model, x, {"normals": nrm, "sdf": sdf}, w, 100)
+        total = torch.zeros((1, 1), device="cuda:0")
+        for l in loss.values():
+            total += l
+        total.backward()
+        opt.step()
+        hist.append([l.item() for l in loss.values()])
     hist = np.array(hist)
     ref = G[f"{name}_f64_hist"]
-    drift = np.abs(G[f"{name}_f32_hist"] - ref).max() / np.abs(ref).max()
+    drift = np.abs(G[f"{name}_f32_hist"] - ref).max(axis=1) / np.abs(ref).max(axis=1)     # the reference's own fp32 run
     per_step = np.abs(hist - ref).max(axis=1) / np.abs(ref).max(axis=1)
     et = rel(model.flat_parameters().cpu().numpy()[G["sample"]], G[f"{name}_f64_theta_sample"])
-    print(f"beetle {name}: per-step curve err {np.array2string(per_step, precision=1)}; theta err {et:.2e}; "
-          f"reference fp32 drift {drift:.2e}")
-    # Adam's first steps are sign-like (g / (|g| + 1e-8)): a parameter whose gradient sits below the fp32 noise floor
-    # (~1e-4 absolute here, the same for the reference's own fp32 run: tests/golden g2 f32-vs-f64) can take the other
-    # sign, which moves the NEXT loss by ~1e-6 relative and then grows chaotically.  Measured on MI355X: one such
-    # flip at step 0; <1e-4 through step 9; 1e-3 at step 11, while loss and gradient evaluated at IDENTICAL theta
-    # agree with fp64 to 1e-7 / 5e-7 (checked below and in test_hip_parity).  So: 1e-4 over the first 8 steps, and the
-    # whole curve within the larger of 5e-3 and twice the reference's own fp32 drift.
-    assert per_step[:8].max() < max(1e-4, 2.0 * drift)
-    assert per_step.max() < max(5e-3, 2.0 * drift)
+    print(f"beetle {name} [{source}]: per-step curve err {np.array2string(per_step, precision=1)}; theta err {et:.2e}; "
+          f"reference fp32 drift {np.array2string(drift, precision=1)}")
+    if name == "s1eik":
+        assert per_step.max() < 1e-4                      # the north-star bar, all 12 steps
+        assert per_step.max() < 5e-6 and et < 1e-5        # ... and what the build actually holds, with margin
+    else:
+        assert per_step[:2].max() < 5e-4                  # before the chaos sets in (reference fp32: 3e-6 at step 1)
+        assert per_step.max() < 2.0 * drift.max()
     # same-theta parity at the END of the run: HIP loss at the trained parameters vs the fp64 oracle at the same ones
     from oracle import dudf_oracle as O
-    x, nrm, sdf = ds.sample(int(G["steps"]))
+    x, nrm, sdf = batches[-1]
     theta = model.flat_parameters().cpu().numpy().astype(np.float64)
     P = synth.unflatten_params(theta, hidden)
-    xo, no, so = [t.cpu().numpy().astype(np.float64) for t in (x, nrm, sdf)]
+    xo, no, so = [t.reshape(-1, t.shape[-1]).cpu().numpy().astype(np.float64) for t in (x, nrm, sdf)]
     t_ref, g_ref, _ = O.loss_and_grad("s1", P, xo, no, so.reshape(-1, 1), w, 100.0)
     model.zero_grad()
-    loss = loss_s1(model, x[None], {"normals": nrm[None], "sdf": sdf[None, :, None]}, w, 100)
+    loss = loss_s1(model, x, {"normals": nrm, "sdf": sdf}, w, 100)
     sum(loss.values()).backward()
     got = np.array([l.item() for l in loss.values()])
     assert rel(got, [float(v) for v in t_ref.values()]) < 1e-5
     gh = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in model.parameters()])
     gr = np.concatenate([np.concatenate([a.reshape(-1), b.reshape(-1)]) for a, b in g_ref])
     assert rel(gh, gr) < (5e-4 if name == "s1full" else 1e-4)
+
+
+def test_beetle_training_engine_path(golden_dir):
+    """The same 12 Eikonal steps through the flat-buffer TrainEngine (dudf_loss_forward/backward + dudf_adam_step,
+    what bench.py times): within 1e-4 of the reference's curve on the fixture's batches."""
+    from diffudf_amd.engine import TrainEngine
+    G = np.load(os.path.join(golden_dir, "g5_beetle.npz"))
+    hidden = list(G["hidden"])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")  # noqa: E731
+    theta = d(synth.flatten_params(synth.siren_params(hidden, seed=int(G["param_seed"]))))
+    eng = TrainEngine(hidden, theta)
+    hist = []
+    for x, n_, s in _fixture_batches(G):
+        hist.append(eng.step(0, d(x), d(n_), d(s[:, 0]), [1e4, 1e4, 0.0, 1e3], 100.0, 1e-4).cpu().numpy().copy())
+    ref = G["s1eik_f64_hist"]
+    per_step = np.abs(np.array(hist) - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    et = rel(theta.cpu().numpy()[G["sample"]], G["s1eik_f64_theta_sample"])
+    print(f"beetle s1eik [TrainEngine]: per-step {np.array2string(per_step, precision=1)}; theta err {et:.2e}")
+    assert per_step.max() < 1e-4 and et < 1e-4

@@ -196,6 +196,31 @@ def test_adam_step_matches_torch_semantics(hip):
     assert rel(th.cpu().numpy(), ref) < 1e-6
 
 
+def test_adam_step_tracks_torch_optim_adam(hip):
+    """dudf_adam_step against torch.optim.Adam ON THE GPU (what the reference loop runs, train.py:334-337): the same
+    operations with the same constants, so after 12 steps theta differs by rounding-order effects only (a 1 - beta2
+    formed in float would show up here as 1e-5)."""
+    rng = np.random.default_rng(3)
+    n = 40013
+    theta = (rng.standard_normal(n) * 5e-3).astype(np.float32)
+    p = torch.nn.Parameter(dev(theta.copy()))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    th = dev(theta.copy()); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for t in range(1, 13):
+        g = dev((rng.standard_normal(n) * 10.0 ** rng.uniform(-2, 2, n)).astype(np.float32))
+        p.grad = g.clone()
+        opt.step()
+        hip.adam_step(th, g, m, v, t, 1e-4)
+    a, b = th.cpu().numpy().astype(np.float64), p.detach().cpu().numpy().astype(np.float64)
+    st = opt.state[p]
+    em = rel(m.cpu().numpy(), st["exp_avg"].cpu().numpy()); ev = rel(v.cpu().numpy(), st["exp_avg_sq"].cpu().numpy())
+    print(f"adam vs torch.optim.Adam after 12 steps: theta {rel(a, b):.2e} (identical: {np.array_equal(a, b)}), "
+          f"exp_avg {em:.2e}, exp_avg_sq {ev:.2e}")
+    assert rel(a, b) < 2e-7 and em < 5e-7 and ev < 5e-7
+    # in units of the update itself (12 steps of ~lr each): well under a percent of one step
+    assert np.abs(a - b).max() < 1e-2 * 1e-4
+
+
 def test_unsupported_configs_fail_loudly(hip):
     from diffudf_amd import _lib
     cfg = hip.make_cfg([64] * 2)

@@ -57,3 +57,17 @@ def test_siren_init_distributions_and_state_dict_layout():
           ((f"net.{i}.0.weight", wt), (f"net.{i}.0.bias", b))}
     m.load_state_dict(sd)
     assert np.array_equal(m.flat_parameters().numpy(), synth.flatten_params(P))
+
+
+def test_normalize_matches_reference_fixture(golden_dir):
+    """reference src/util.py:34-39: 1-D -> v/|v|; 2-D -> each ROW by its own norm (g8_operators.npz holds the
+    reference function's outputs)."""
+    import os
+    from diffudf_amd.util import normalize
+    from src.util import normalize as shim
+    G = np.load(os.path.join(golden_dir, "g8_operators.npz"))
+    assert np.array_equal(normalize(G["norm_in_2d"]), G["norm_out_2d"])
+    assert np.array_equal(normalize(G["norm_in_1d"]), G["norm_out_1d"])
+    assert np.array_equal(shim(G["norm_in_2d"]), G["norm_out_2d"])
+    rows = np.linalg.norm(normalize(G["norm_in_2d"]), axis=1)
+    assert np.abs(rows - 1).max() < 1e-12

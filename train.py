@@ -50,16 +50,34 @@ def _dist():
     return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
-def _allreduce_grads(model):
-    """Every rank holds its share sum_local/n_global of the gradient: one all-reduce(sum) of the flat buffer."""
+def _zero_flat_grad(model):
+    """`optim.zero_grad()` for the flat layout: every p.grad is a view of ONE buffer [dtheta | 4 loss terms], zeroed
+    by one memset; backward() accumulates into the views in place, and that buffer is what gets all-reduced — no
+    per-step torch.cat / copy-back."""
+    flat = getattr(model, "_dudf_flat_grad", None)
+    theta = model.flat_parameters()
+    if flat is None or flat.device != theta.device or flat.numel() != theta.numel() + 4:
+        flat = model._dudf_flat_grad = torch.zeros(theta.numel() + 4, dtype=torch.float32, device=theta.device)
+    else:
+        flat.zero_()
+    views = model.split_flat(flat[:theta.numel()])
+    for p, v in zip(model.parameters(), views):
+        if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+            p.grad = v
+    return flat
+
+
+def _allreduce_step(flat, vals, terms_are_global):
+    """Every rank holds its share sum_local/n_global of the gradient and of each loss term: ONE all-reduce(sum) of the
+    flat [dtheta | terms] buffer.  loss_s2's terms are already global (its statistics were all-reduced between the
+    forward and the backward, every rank computed identical terms), so they stay out of the sum."""
     if not _dist() or torch.distributed.get_world_size() == 1:
-        return
-    grads = [p.grad for p in model.parameters()]
-    flat = torch.cat([g.reshape(-1) for g in grads])
+        return vals
+    n, k = vals.numel(), flat.numel() - 4
+    if not terms_are_global:
+        flat[k:k + n] = vals
     torch.distributed.all_reduce(flat)
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+    return vals if terms_are_global else flat[k:k + n].clone()
 
 
 def _is_main():
@@ -92,7 +110,7 @@ def _train(dataset, model, device, config, schedule):
                 g['lr'] = current_lr
         running_loss = dict()
         for input_data, normals, sdf in iter(dataset):
-            optim.zero_grad()
+            flat_grad = _zero_flat_grad(model)
             input_data = input_data.to(device); normals = normals.to(device); sdf = sdf.to(device)
             loss = loss_fn(model, input_data, {'normals': normals, 'sdf': sdf}, loss_weights, *extra)
             train_loss = torch.zeros((1, 1), device=device)
@@ -100,9 +118,7 @@ def _train(dataset, model, device, config, schedule):
             for l in loss.values():
                 train_loss += l
             train_loss.backward()
-            _allreduce_grads(model)
-            if _dist():
-                torch.distributed.all_reduce(vals)
+            vals = _allreduce_step(flat_grad, vals, terms_are_global=loss_fn is loss_s2)
             optim.step()
             vals = vals.tolist()                       # ONE device->host sync per step (the reference does five)
             for (it, _), v in zip(loss.items(), vals):
@@ -172,9 +188,18 @@ def setup_train(parameter_dict, cuda_device):
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         cuda_device = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(cuda_device)
+        # DUDF_TEST_SHARE_GPU=1: functional check of the N>1 path on a ONE-GPU box (every rank on the given device, gloo
+        # instead of RCCL, which refuses two ranks on one device).  Never set for a measurement.
+        share = os.environ.get("DUDF_TEST_SHARE_GPU") == "1"
+        if share:
+            cuda_device = 0
+            torch.cuda.set_device(0)
         if not _dist():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", cuda_device))
+            if share:
+                torch.distributed.init_process_group("gloo")
+            else:
+                torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", cuda_device))
         rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
     device = torch.device("cuda", int(cuda_device))
     seed = 123
