@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, co
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float w1, float b2, float w2, float eps, float step_size,
                                                    float bc2_sqrt, float gscale) {
+#pragma clang fp contract(off)                                   // only the fmaf below fuse (HIP's __fmul_rn etc. are plain operators)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = fmaf(w1, gi - m[i], m[i]);               // lerp_(grad, 1 - beta1), weight < 0.5 branch

@@ -99,6 +99,10 @@ __device__ __forceinline__ double tri_dist2(double px, double py, double pz, con
 constexpr int TRI_TILE = 256;
 
 __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
+    // no a*b+c -> fma here: the oracle (numpy) rounds the product of normal and offset to fp32 before the add, and HIP's
+    // __fmul_rn / __fadd_rn are plain operators that hipcc's default -ffp-contract=fast would fuse (measured: 48 of 999
+    // near points off by one ulp)
+#pragma clang fp contract(off)
     __shared__ float tl[TRI_TILE * 9];
     const int64_t n_on_l = a.on1 - a.on0, n_far_l = a.far1 - a.far0, n_near_l = a.near1 - a.near0;
     const int64_t n_l = n_on_l + n_far_l + n_near_l;

@@ -387,7 +387,13 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
 // order ([operand][piece][32-feature block][column half][feature][8 columns]: a fragment is two lane-linear 512-byte
 // halves, conflict-free for ds_read_b128; the halves are 528 bytes apart so that the 8-byte writes do not collide).  The image is double buffered (2 x 48 KiB); one barrier per stage; the next stage's split runs in
 // front of this stage's MFMAs while the stage after that is in flight in registers.
-template <int H>
+// VAR bit 0: producer lanes are dealt out so that each ds_write_b64 wave-instruction is bank-conflict free (a 16-lane
+//   service group spans offsets 16 a + 2 b + 4 c + 8 d dwords: fq bit 0 | column-group bit 0 | column half | fq bit 3);
+//   the plain (tid >> 2) order put feature quads 0/2 and 1/3 of a group on the same banks (PMC r01: 29 % of LDS cycles).
+// VAR bit 1: the split of the next stage is cut into four feature slices issued BETWEEN the four MFMA groups of this
+//   stage instead of in front of them: the two waves of a SIMD then leave the post-barrier lockstep (both splitting,
+//   matrix core idle) after the first slice — one wave's slice runs beside the other's MFMAs.
+template <int H, int VAR>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p_kernel(WgradArgs a) {
     using W = WG<H>;
     static_assert(H == 256, "256 x 256 output tiles");
@@ -431,7 +437,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
 
     // producer role of this lane: operand, feature quad, group of four columns
     const int p_oper = wave / (NW_ / 2);                                  // wave-uniform: waves 0..3 stage X, 4..7 stage Y
-    const int p_fq = (tid >> 2) & (FQ - 1), p_cg = tid & 3;
+    const int p_cg = tid & 3;
+    const int p_fq = (VAR & 1) ? (((tid >> 2) & 1) | (((tid >> 4) & 3) << 1) | (((tid >> 3) & 1) << 3) | (((tid >> 6) & 3) << 4))
+                               : ((tid >> 2) & (FQ - 1));
     const int64_t p_goff = ((int64_t)p_fq * a.np + 4 * p_cg) * 4;         // floats, + col0 * 4 per stage
     // image of one piece: [32-feature block][column half][feature in block][8 columns] = the fragment order of the MFMA
     const int p_loff = p_oper * OPERB + (p_fq >> 3) * BLKB + (p_cg >> 1) * HALFB + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
@@ -460,29 +468,28 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     auto wait_raw = [&](RawSet& r, auto younger) {       // this set has landed; `younger` loads issued after it stay in flight
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.g0), "+v"(r.g1), "+v"(r.g2), "+v"(r.g3) : "n"(decltype(younger)::value));
     };
+    auto split_slice = [&](int it, const RawSet& r, int f) {              // feature f of the lane's quad -> piece image buffer it & 1
+        char* dst = ldsb + (it & 1) * BUFB + p_loff + 16 * f;
+        if (f == 0) {
+            const bool hstage = (int64_t)step_of(it) * KB < a.ncol_h;     // Hessian quads: only columns % 4 == 0 carry the bias
+            const float bm = (p_oper == 0 && pair_of(it) == 1 && i_off == 0) ? 1.f : 0.f;
+            const float bo = hstage ? 0.f : bm;
+            bacc += bm * r.g0 + bo * (r.g1 + r.g2 + r.g3);
+        }
+        const f32x2 v0 = {r.g0[f], r.g1[f]}, v1 = {r.g2[f], r.g3[f]};     // four columns of one feature -> 3 x 8 bytes
+        const unsigned h0 = cvt_pk(v0), h1 = cvt_pk(v1);
+        const f32x2 r0 = v0 - unpack(h0), r1 = v1 - unpack(h1);
+        const unsigned m0 = cvt_pk(r0), m1 = cvt_pk(r1);
+        const f32x2 q0 = r0 - unpack(m0), q1 = r1 - unpack(m1);
+        const unsigned l0 = cvt_pk(q0), l1 = cvt_pk(q1);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(dst + PIECEB) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(dst + 2 * PIECEB) = u32x2{l0, l1};
+    };
     auto split_store = [&](int it, const RawSet& r) {                     // raw (stage it) -> piece image buffer it & 1
-        const f32x4 raw0 = r.g0, raw1 = r.g1, raw2 = r.g2, raw3 = r.g3;
-        char* dst = ldsb + (it & 1) * BUFB + p_loff;
-        const bool hstage = (int64_t)step_of(it) * KB < a.ncol_h;         // Hessian quads: only columns % 4 == 0 carry the bias
-        const float bm = (p_oper == 0 && pair_of(it) == 1 && i_off == 0) ? 1.f : 0.f;
-        const float bo = hstage ? 0.f : bm;
-        bacc += bm * raw0 + bo * (raw1 + raw2 + raw3);
-        auto one = [&](float c0, float c1, float c2, float c3, char* d) {   // four columns of one feature -> 3 x 8 bytes
-            const f32x2 v0 = {c0, c1}, v1 = {c2, c3};
-            const unsigned h0 = cvt_pk(v0), h1 = cvt_pk(v1);
-            const f32x2 r0 = v0 - unpack(h0), r1 = v1 - unpack(h1);
-            const unsigned m0 = cvt_pk(r0), m1 = cvt_pk(r1);
-            const f32x2 q0 = r0 - unpack(m0), q1 = r1 - unpack(m1);
-            const unsigned l0 = cvt_pk(q0), l1 = cvt_pk(q1);
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d + PIECEB) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2*>(d + 2 * PIECEB) = u32x2{l0, l1};
-        };
-        one(raw0.x, raw1.x, raw2.x, raw3.x, dst);
-        one(raw0.y, raw1.y, raw2.y, raw3.y, dst + 16);
-        one(raw0.z, raw1.z, raw2.z, raw3.z, dst + 32);
-        one(raw0.w, raw1.w, raw2.w, raw3.w, dst + 48);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) split_slice(it, r, f);
     };
     // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
     const int c_lane = (lane >> 5) * HALFB + (lane & 31) * 16;
@@ -505,28 +512,48 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     // stages = 96 KiB per CU stay in flight: with one, the kernel measured latency-bound at 2 TB/s), then 48 MFMAs
     auto stage = [&](int it, RawSet& r, auto hot) {
         const char* buf = ldsb + (it & 1) * BUFB;
-        if constexpr (decltype(hot)::value) {     // steady state: the two younger sets (8 loads) stay in flight
-            wait_raw(r, std::integral_constant<int, 8>{});
-            split_store(it + 1, r);
-            load_raw(it + 4, r);
-        } else if (it + 1 < nit) {
-            split_store(it + 1, r);
-            if (it + 4 < nit) load_raw_plain(it + 4, r);
+        constexpr bool HOT = decltype(hot)::value;
+        constexpr bool IL = (VAR & 2) != 0;
+        static_assert(!IL || W::NTL == 4, "one split slice per MFMA group");
+        const bool more = HOT || it + 1 < nit;
+        if constexpr (!IL) {
+            if constexpr (HOT) {                  // steady state: the two younger sets (8 loads) stay in flight
+                wait_raw(r, std::integral_constant<int, 8>{});
+                split_store(it + 1, r);
+                load_raw(it + 4, r);
+            } else if (more) {
+                split_store(it + 1, r);
+                if (it + 4 < nit) load_raw_plain(it + 4, r);
+            }
         }
         bf16x8 af[W::MT][3], bn[3];
 #pragma unroll
         for (int m = 0; m < W::MT; ++m)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) af[m][pc] = fragA(buf, m, pc);
+        if constexpr (!IL) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, 0, pc);
+            for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, 0, pc);
+        }
 #pragma unroll
         for (int n = 0; n < W::NTL; ++n) {
-            const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
-            if (n + 1 < W::NTL) {
+            if constexpr (IL) {
+                // this group's B fragments, then slice n of the next stage's split (its VALU covers the read latency: no
+                // second fragment set in registers), then this group's MFMAs
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n + 1, pc);
-                __builtin_amdgcn_sched_barrier(0x76);            // LDS reads and MFMAs keep their order: fragments one block ahead
+                for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n, pc);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (HOT) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
+                if (more) split_slice(it + 1, r, n);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
+            if constexpr (!IL) {
+                if (n + 1 < W::NTL) {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n + 1, pc);
+                    __builtin_amdgcn_sched_barrier(0x76);        // LDS reads and MFMAs keep their order: fragments one block ahead
+                }
             }
 #pragma unroll
             for (int m = 0; m < W::MT; ++m) {
@@ -539,6 +566,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
                 c = mfma_bf16(af[m][0], bh, c);
                 acc[m][n] = c;
             }
+            if constexpr (IL) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (IL) {
+            if constexpr (HOT) load_raw(it + 4, r);
+            else if (it + 4 < nit) load_raw_plain(it + 4, r);
         }
         __syncthreads();
     };
@@ -704,13 +736,25 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
             if (!per_wave) {
                 static bool attr3 = false;
                 const size_t smem_p = 2 * 2 * 3 * (size_t)(H / 32) * 2 * (32 * 16 + 16);   // 2 buffers x (X | Y) x 3 pieces x blocks
+                // DUDF_WGRAD_VAR=0..3 (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split; default 3
+                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 3 : 3; }();
                 if (!attr3) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+                    hipError_t e = hipSuccess;
+                    const void* fns[4] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 2>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>)};
+                    for (int v = 0; v < 4 && e == hipSuccess; ++v)
+                        e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
                 }
-                hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a);
+                switch (var) {
+                    case 0: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 0>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
+                    case 1: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 1>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
+                    case 2: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 2>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
+                    default: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 3>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
+                }
                 return (int)hipGetLastError();
             }
         }

@@ -214,6 +214,35 @@ def grid_fields(cfg, theta, grid_n, start, count, gt_mode, alpha, out_df, out_ve
     return flag
 
 
+def capudf_extract(ndf, grad, threshold=0.008, want_cells=False):
+    """CAP-UDF cell extraction (reference src/render_mc.py:201-256) on device fields ndf (N,N,N), grad (N,N,N,3):
+    (vertices (V,3) float64 in [-1,1]^3, triangles (T,3) int64[, cells (C,3) int64]) device tensors.  One host sync
+    for the three output sizes."""
+    lib = _lib.load()
+    ndf = _f32(ndf, "ndf"); grad = _f32(grad, "grad")
+    n = ndf.shape[0]
+    if ndf.shape != (n, n, n) or grad.shape != (n, n, n, 3):
+        raise _lib.DudfError(f"capudf_extract: ndf (N,N,N) and grad (N,N,N,3) expected, got {tuple(ndf.shape)}, {tuple(grad.shape)}")
+    dev = ndf.device
+    nbytes = int(lib.dudf_capudf_workspace_bytes(n))
+    if nbytes == 0:
+        _lib.check(-1, "dudf_capudf_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.dudf_capudf_count(_ptr(ndf), _ptr(grad), n, float(threshold), _ptr(counts), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "dudf_capudf_count")
+        nc, nv, nt = [int(v) for v in counts.tolist()]
+        verts = torch.empty(nv, 3, dtype=torch.float64, device=dev)
+        tris = torch.empty(nt, 3, dtype=torch.int64, device=dev)
+        cells = torch.empty(nc, 3, dtype=torch.int64, device=dev) if want_cells else None
+        if nc:
+            rc = lib.dudf_capudf_emit(_ptr(ndf), _ptr(grad), n, float(threshold), _ptr(verts), _ptr(tris), _ptr(cells),
+                                      _ptr(ws), nbytes, _stream())
+            _lib.check(rc, "dudf_capudf_emit")
+    return (verts, tris, cells) if want_cells else (verts, tris)
+
+
 def _w4(weights):
     w = list(weights) + [0.0] * (4 - len(weights))
     return (ctypes.c_double * 4)(*[float(v) for v in w])

@@ -1,7 +1,8 @@
 # coding: utf-8
-"""Field extraction for the marching-cubes consumers — the query half of reference src/render_mc.py:20-99
-`extract_fields` (BASELINE config 5).  The mesh extraction itself (CAP-UDF / MeshUDF marching cubes, :103-256)
-is outside this build's scope."""
+"""Field extraction and CAP-UDF meshing for the marching-cubes consumers — reference src/render_mc.py:20-99
+`extract_fields` and :201-256 `extract_mesh_CAP` (BASELINE config 5: the batched field+gradient query feeding CAP-UDF
+extraction, all on the device).  MeshUDF's marching cubes (:103-199) is not part of this path."""
+import numpy as np
 import torch
 
 from . import hip_ops
@@ -46,3 +47,48 @@ def extract_fields(decoder, latent_vec, N, gt_mode, device, alpha, chunk=1 << 20
         sign = torch.where((vec[bad] * n_hat).sum(-1, keepdim=True) < 0, -1.0, 1.0)
         vec[bad] = sign * n_hat
     return df.reshape(N, N, N), vec.reshape(N, N, N, 3)
+
+
+class TriangleSoup:
+    """What `extract_mesh_CAP` returns when `trimesh` is not installed: the two arrays a `trimesh.Trimesh(v, f,
+    process=False)` would hold, plus OBJ / PLY export (the reference only ever calls `.export(path)` and reads
+    `.vertices` / `.faces`, generate_mc.py:60-75)."""
+
+    def __init__(self, vertices, faces):
+        self.vertices = np.asarray(vertices, dtype=np.float64)
+        self.faces = np.asarray(faces, dtype=np.int64)
+
+    def export(self, path):
+        v, f = self.vertices, self.faces
+        if str(path).endswith(".ply"):
+            with open(path, "w") as fo:
+                fo.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+                         "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(v), len(f)))
+                np.savetxt(fo, v, fmt="%.17g")
+                np.savetxt(fo, np.concatenate([np.full((len(f), 1), 3), f], 1), fmt="%d")
+        else:
+            with open(path, "w") as fo:
+                np.savetxt(fo, v, fmt="v %.17g %.17g %.17g")
+                np.savetxt(fo, f + 1, fmt="f %d %d %d")
+        return path
+
+
+def extract_mesh_CAP(ndf, grad, resolution, threshold=0.008, device=None):
+    """Same signature as reference src/render_mc.py:201 (`ndf` (N,N,N), `grad` (N,N,N,3): numpy arrays or tensors — the
+    outputs of `extract_fields` can be passed straight through without leaving the device).  Active-cell test, sign by
+    gradient, per-cell marching cubes and compaction run in `dudf_capudf_count` / `dudf_capudf_emit`; returns a
+    `trimesh.Trimesh(process=False)` when trimesh is importable, else a `TriangleSoup` with the same two arrays."""
+    dev = torch.device(device) if device is not None else (ndf.device if torch.is_tensor(ndf) and ndf.is_cuda else torch.device("cuda", 0))
+    if dev.type != "cuda":
+        raise DudfError("extract_mesh_CAP: needs the GPU; there is no CPU fallback path")
+    t = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev)   # noqa: E731
+    d, g = t(ndf), t(grad)
+    if d.shape[0] != resolution:
+        raise ValueError("resolution does not match the field")
+    v, f = hip_ops.capudf_extract(d, g, threshold)
+    v, f = v.cpu().numpy(), f.cpu().numpy()
+    try:
+        import trimesh
+        return trimesh.Trimesh(v, f, process=False)
+    except ImportError:
+        return TriangleSoup(v, f)

@@ -114,6 +114,24 @@ int dudf_grid_fields(const dudf_net_cfg* cfg, const float* theta, int64_t grid_n
                      int inverse_mode, double alpha, float* out_df, float* out_vec, int* out_flag_count,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* CAP-UDF cell extraction — replaces the per-cell Python loop of `extract_mesh_CAP(ndf, grad, resolution)` (reference
+ * src/render_mc.py:201-256) on the fields dudf_grid_fields produced, which stay on the device:
+ *   ndf (grid_n^3) float, grad (grid_n^3, 3) float, first grid axis slowest;  threshold = 0.008 in the reference (:205).
+ * A cell is emitted when min(ndf over its 8 corners) <= threshold and, with every corner signed by
+ * dot(grad[corner 000], grad[corner]) < 0 (:224), some corner is negative (:230); it then contributes the vertices and
+ * triangles of marching cubes at iso 0 on its 2x2x2 values, shifted by its index and mapped to [-1,1]^3 (:236-252), in
+ * the reference's (i, j, k) loop order.  The per-cell marching cubes replaces `mcubes.marching_cubes` (PyMCubes,
+ * third-party, absent here; conventions and table: oracle/capudf_oracle.py, tools/gen_mc_table.py).
+ * Two calls because the output size is data dependent:
+ *   dudf_capudf_count -> out_counts (device, 3 x int64): emitted cells, vertices, triangles;
+ *   dudf_capudf_emit  -> out_vertices (V,3) double, out_triangles (T,3) int64 (indices into out_vertices),
+ *                        out_cells (C,3) int64 or NULL; same ndf / grad / threshold / workspace as the count call. */
+size_t dudf_capudf_workspace_bytes(int64_t grid_n);
+int dudf_capudf_count(const float* ndf, const float* grad, int64_t grid_n, double threshold, int64_t* out_counts,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int dudf_capudf_emit(const float* ndf, const float* grad, int64_t grid_n, double threshold, double* out_vertices,
+                     int64_t* out_triangles, int64_t* out_cells, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Forward half of loss_s1 / loss_siren (reference src/loss_functions.py:123-155, :82-104):
  * SIREN forward, df/dx, the four weighted loss terms.  out_terms (device, 4 floats) receives
  * THIS RANK's share  sum_local(term_i) * weight / n_global  in the reference's dict order

@@ -98,14 +98,14 @@ def _vregs(tok):
     return out
 
 
-def analyse_wgrad_presplit(asm_path):
+def analyse_wgrad_presplit(asm_path, var=0):
     """wgrad_hidden_bf16p_kernel<256> stages the stash through REGISTERS with inline-asm loads and hand-counted vmcnt
     waits inside its steady-state loop (hipcc does not know those registers are in flight).  Finds that loop (the
     self-looping basic block that holds the MFMAs and the asm loads), replays it twice with a FIFO of the loads — the
     second pass starts with what the first left in flight — and returns the instructions that touch a destination
     register of a load still in flight (must be none), the loads per pass and the loads in flight across the back edge."""
     txt = open(asm_path).read()
-    m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256E\w*):", txt, re.M)
+    m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
     body = txt[m.end():txt.index("s_endpgm", m.end())].split("\n")
     blocks, cur, name = [], [], "entry"
     for ln in body:
@@ -153,4 +153,5 @@ def analyse_wgrad_presplit(asm_path):
     bad1, loads = replay(fifo)
     carried = len(fifo)
     bad2, _ = replay(fifo)
-    return {"bad": bad1 + bad2, "loads": loads, "carried": carried}
+    scratch = sum(1 for _, b in blocks for x in b if x.startswith("scratch_"))
+    return {"bad": bad1 + bad2, "loads": loads, "carried": carried, "scratch": scratch}

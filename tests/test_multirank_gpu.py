@@ -9,6 +9,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -25,28 +26,37 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, args, timeout=900):
+def _launch(world, args, timeout=300):
     port = _free_port()
-    procs = []
+    procs, logs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), DUDF_TEST_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         if world == 1:
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k)
-        procs.append(subprocess.Popen([sys.executable, WORKER] + args, env=env, cwd=REPO, stdout=subprocess.PIPE,
+        logs.append(tempfile.NamedTemporaryFile("w+", suffix=f".rank{r}.log", delete=False))
+        procs.append(subprocess.Popen([sys.executable, WORKER] + args, env=env, cwd=REPO, stdout=logs[-1],
                                       stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
+    import time
+    t0 = time.time()
+    while any(p.poll() is None for p in procs):
+        # one dead rank leaves the others waiting in a collective: stop them instead of sitting out the timeout
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() - t0 > timeout:
+            time.sleep(2.0)
             for q in procs:
-                q.kill()
-            raise
-        outs.append(o)
+                if q.poll() is None:
+                    q.kill()
+            break
+        time.sleep(0.2)
+    outs = []
+    for p, f in zip(procs, logs):
+        p.wait()
+        f.flush(); f.seek(0)
+        outs.append(f.read())
+        f.close(); os.unlink(f.name)
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r}/{world} failed:\n{o[-3000:]}"
+        assert p.returncode == 0, f"rank {r}/{world} failed (rc {p.returncode}):\n{o[-3000:]}"
     return outs
 
 

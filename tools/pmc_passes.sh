@@ -1,6 +1,8 @@
 # rocprofv3 counter passes over bench.py (one counter group per pass); usage: bash tools/pmc_passes.sh [set]
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 SET=${1:-core}
 if [ "$SET" = core ]; then
 CSETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \

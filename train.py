@@ -186,14 +186,11 @@ def setup_train(parameter_dict, cuda_device):
         raise SystemExit("train.py: no GPU visible; the HIP training path has no CPU fallback")
     rank = world = None
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        cuda_device = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(cuda_device)
-        # DUDF_TEST_SHARE_GPU=1: functional check of the N>1 path on a ONE-GPU box (every rank on the given device, gloo
-        # instead of RCCL, which refuses two ranks on one device).  Never set for a measurement.
+        # DUDF_TEST_SHARE_GPU=1: functional check of the N>1 path on a ONE-GPU box (every rank on device 0, gloo instead
+        # of RCCL, which refuses two ranks on one device).  Never set for a measurement.
         share = os.environ.get("DUDF_TEST_SHARE_GPU") == "1"
-        if share:
-            cuda_device = 0
-            torch.cuda.set_device(0)
+        cuda_device = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(cuda_device)
         if not _dist():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if share:
