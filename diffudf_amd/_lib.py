@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdudf_hip.so")
+# DUDF_LIB: another build of the same library (timing experiments with debug knobs compiled in); default: the in-tree one
+LIB_PATH = os.environ.get("DUDF_LIB") or os.path.join(_HERE, "libdudf_hip.so")
 
 LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
 

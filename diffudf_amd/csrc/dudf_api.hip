@@ -59,6 +59,8 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.L = lo.L; a.w0 = lo.w0;
     a.store_s = 0; a.store_c = 0; a.train = 0; a.have_e = 1;
     a.tile0 = 0; a.ntiles = 0; a.hess = 0;
+    static const int prio = [] { const char* e = getenv("DUDF_SWEEP_PRIO"); return e ? atoi(e) : 0; }();
+    a.prio = prio;
     return a;
 }
 

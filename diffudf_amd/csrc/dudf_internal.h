@@ -117,6 +117,7 @@ struct SweepArgs {
     int L; float w0;
     int store_s, store_c, train;   // what the sweep has to leave behind
     int have_e;                    // reverse adjoint sweep: e_l was produced by SWEEP_ADJ_FWD
+    int prio;                      // bf16 sweeps: static priority for waves 0-3 of a workgroup (stagger of the SIMD partners)
 };
 
 enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,

@@ -349,6 +349,11 @@ template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
+    // the two waves of a SIMD (w, w + 4) leave every k-block barrier in lockstep: tails coincide, MFMA streams collide.
+    // A static priority for one half lets it run its tail first at every contended issue slot; the partner falls one tail
+    // behind and from then on overlaps its tail with the other's MFMAs (MI355X_MICROARCH.md, "two waves per SIMD", 4 and 9)
+    if (a.prio == 1) { if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(1); }
+    else if (a.prio == 2) { if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1); }
     // balanced shares of 16-column groups; a share is walked in passes of 8 groups, the last one possibly partial —
     // a pass with one wave per SIMD (or a single wave) costs about half a full one, a whole extra round would cost all of it
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);

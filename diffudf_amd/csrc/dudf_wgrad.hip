@@ -393,6 +393,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
 // VAR bit 1: the split of the next stage is cut into four feature slices issued BETWEEN the four MFMA groups of this
 //   stage instead of in front of them: the two waves of a SIMD then leave the post-barrier lockstep (both splitting,
 //   matrix core idle) after the first slice — one wave's slice runs beside the other's MFMAs.
+#ifndef DUDF_WGRAD_DBG
+#define DUDF_WGRAD_DBG 0           // timing experiments only (wrong results): 1 no loads, 2 no barrier, 4 no MFMA, 8 no split,
+#endif                             // 16 no LDS fragment reads
 template <int H, int VAR>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p_kernel(WgradArgs a) {
     using W = WG<H>;
@@ -440,7 +443,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     const int p_cg = tid & 3;
     const int p_fq = (VAR & 1) ? (((tid >> 2) & 1) | (((tid >> 4) & 3) << 1) | (((tid >> 3) & 1) << 3) | (((tid >> 6) & 3) << 4))
                                : ((tid >> 2) & (FQ - 1));
-    const int64_t p_goff = ((int64_t)p_fq * a.np + 4 * p_cg) * 4;         // floats, + col0 * 4 per stage
+    // granule j of this lane = stage column p_cg + 4 j: one load instruction then reads 64 contiguous bytes per feature
+    // quad (4 lanes x 16 B) and touches each 128-byte line twice instead of four times (PMC r01: 2x the ideal L2
+    // requests; the loads alone held the kernel at 0.8 ms).  The image slot 4 p_cg + j therefore holds column p_cg + 4 j:
+    // a permutation of the contraction index, the same for both operands, hence free.
+    const int64_t p_goff = ((int64_t)p_fq * a.np + p_cg) * 4;             // floats, + col0 * 4 per stage
     // image of one piece: [32-feature block][column half][feature in block][8 columns] = the fragment order of the MFMA
     const int p_loff = p_oper * OPERB + (p_fq >> 3) * BLKB + (p_cg >> 1) * HALFB + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
     struct RawSet { f32x4 g0, g1, g2, g3; };                              // granule j: 4 features of column 4*cg + j
@@ -450,20 +457,27 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     const float* P1 = p_oper ? Y1 : X1;
     // Inline asm + hand-counted vmcnt (as in the sweeps): with compiler-visible loads hipcc drains ALL stages in flight
     // (vmcnt(0)) at the loop head.  These twelve loads are the only vector-memory operations of the loop.
+    // scalar base (operand, pair, stage: wave-uniform) + this lane's fixed 32-bit byte offset: no per-stage 64-bit address
+    // arithmetic in vector registers (the launcher keeps FQ * np * 16 below 2^32)
+    const unsigned p_voff = (unsigned)(p_goff * 4);
+    const float bm_plain = (p_oper == 0 && i_off == 0) ? 1.f : 0.f;     // this lane's granules count towards the bias gradient ...
+    const float bm_quad = (p_cg == 0) ? bm_plain : 0.f;                  // ... on a Hessian-quad stage
     auto load_raw = [&](int it, RawSet& r) {
-        const float* src = (pair_of(it) ? P1 : P0) + p_goff + (int64_t)step_of(it) * KB * 4;
-        asm volatile("global_load_dwordx4 %0, %4, off nt\n\tglobal_load_dwordx4 %1, %4, off offset:16 nt\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:32 nt\n\tglobal_load_dwordx4 %3, %4, off offset:48 nt"
-                     : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3) : "v"(src) : "memory");
+        const uint64_t g0 = (uint64_t)(size_t)((pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * KB * 4);
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
+        const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
+        asm volatile("global_load_dwordx4 %0, %4, %5 nt\n\tglobal_load_dwordx4 %1, %4, %5 offset:64 nt\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:128 nt\n\tglobal_load_dwordx4 %3, %4, %5 offset:192 nt"
+                     : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3) : "v"(p_voff), "s"(sbase) : "memory");
     };
     // outside the steady-state loop (prologue, last stages: conditional loads) the loads are ordinary ones: a conditional
     // asm load makes hipcc merge "loaded" and "not loaded" values with register copies — of registers still in flight
     auto load_raw_plain = [&](int it, RawSet& r) {
         const float* src = (pair_of(it) ? P1 : P0) + p_goff + (int64_t)step_of(it) * KB * 4;
         r.g0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-        r.g1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 1);
-        r.g2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 2);
-        r.g3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 3);
+        r.g1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 4);
+        r.g2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 8);
+        r.g3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 12);
     };
     auto wait_raw = [&](RawSet& r, auto younger) {       // this set has landed; `younger` loads issued after it stay in flight
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.g0), "+v"(r.g1), "+v"(r.g2), "+v"(r.g3) : "n"(decltype(younger)::value));
@@ -471,10 +485,14 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     auto split_slice = [&](int it, const RawSet& r, int f) {              // feature f of the lane's quad -> piece image buffer it & 1
         char* dst = ldsb + (it & 1) * BUFB + p_loff + 16 * f;
         if (f == 0) {
-            const bool hstage = (int64_t)step_of(it) * KB < a.ncol_h;     // Hessian quads: only columns % 4 == 0 carry the bias
-            const float bm = (p_oper == 0 && pair_of(it) == 1 && i_off == 0) ? 1.f : 0.f;
-            const float bo = hstage ? 0.f : bm;
-            bacc += bm * r.g0 + bo * (r.g1 + r.g2 + r.g3);
+            // Hessian quads: only columns % 4 == 0 (the value channel) carry the bias — all four granules of the lanes
+            // with p_cg == 0, none of the others
+            // (branch-free: scalar selects times per-lane constants — a branch here would cut the hand-counted loop body
+            // into several basic blocks)
+            const float hs = ((int64_t)step_of(it) * KB < a.ncol_h) ? 1.f : 0.f;
+            const float pf = pair_of(it) == 1 ? 1.f : 0.f;
+            const float bm = pf * (bm_plain + hs * (bm_quad - bm_plain));
+            bacc += bm * (r.g0 + r.g1 + r.g2 + r.g3);
         }
         const f32x2 v0 = {r.g0[f], r.g1[f]}, v1 = {r.g2[f], r.g3[f]};     // four columns of one feature -> 3 x 8 bytes
         const unsigned h0 = cvt_pk(v0), h1 = cvt_pk(v1);
@@ -494,9 +512,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
     const int c_lane = (lane >> 5) * HALFB + (lane & 31) * 16;
     auto fragA = [&](const char* buf, int m, int pc) -> bf16x8 {
+        if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }     // timing only: no LDS read
         return *reinterpret_cast<const bf16x8*>(buf + pc * PIECEB + (wo * W::MT + m) * BLKB + c_lane);
     };
     auto fragB = [&](const char* buf, int n, int pc) -> bf16x8 {
+        if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
         return *reinterpret_cast<const bf16x8*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
     };
 
@@ -513,6 +533,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     auto stage = [&](int it, RawSet& r, auto hot) {
         const char* buf = ldsb + (it & 1) * BUFB;
         constexpr bool HOT = decltype(hot)::value;
+        constexpr int DBG = HOT ? DUDF_WGRAD_DBG : 0;
         constexpr bool IL = (VAR & 2) != 0;
         static_assert(!IL || W::NTL == 4, "one split slice per MFMA group");
         const bool more = HOT || it + 1 < nit;
@@ -543,8 +564,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n, pc);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (HOT) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
-                if (more) split_slice(it + 1, r, n);
+                if constexpr (HOT && !(DBG & 1)) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
+                if constexpr (!(DBG & 8)) { if (more) split_slice(it + 1, r, n); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
@@ -557,6 +578,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
             }
 #pragma unroll
             for (int m = 0; m < W::MT; ++m) {
+                if constexpr ((DBG & 4) != 0) { asm volatile("" :: "v"(af[m][0]), "v"(af[m][1]), "v"(af[m][2]), "v"(bh), "v"(bmid), "v"(bl)); continue; }
                 f32x16 c = acc[m][n];
                 c = mfma_bf16(af[m][1], bmid, c);                 // smallest terms first
                 c = mfma_bf16(af[m][2], bh, c);
@@ -569,11 +591,16 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
             if constexpr (IL) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (IL) {
-            if constexpr (HOT) load_raw(it + 4, r);
+            if constexpr (HOT) { if constexpr (!(DBG & 1)) load_raw(it + 4, r); }
             else if (it + 4 < nit) load_raw_plain(it + 4, r);
         }
-        __syncthreads();
+        if constexpr (!(DBG & 2)) __syncthreads();
     };
+    // VAR bit 2: static priority for waves 0-3 (their SIMD partners are waves 4-7).  Both waves of a SIMD leave every
+    // barrier in lockstep, so their split slices (VALU, matrix core idle) and their MFMA groups (matrix core contended)
+    // coincide and interleaving alone buys nothing; with one of them served first at every contended issue slot the other
+    // falls behind by one slice and from then on runs its slices beside the partner's MFMAs.  No per-stage flips.
+    if constexpr ((VAR & 4) != 0) { if (wave < NW_ / 2) __builtin_amdgcn_s_setprio(1); }
     int it = 0;                                                  // stage it+1 lives in set (it+1) % 3
     const int nhot = nit >= 7 ? ((nit - 4) / 3) * 3 : 0;
     // hipcc does not know the sets are in flight: enter (and leave) the hand-counted loop with everything landed, so that
@@ -736,25 +763,30 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
             if (!per_wave) {
                 static bool attr3 = false;
                 const size_t smem_p = 2 * 2 * 3 * (size_t)(H / 32) * 2 * (32 * 16 + 16);   // 2 buffers x (X | Y) x 3 pieces x blocks
-                // DUDF_WGRAD_VAR=0..3 (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split; default 3
-                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 3 : 3; }();
+                // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7} (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split,
+                // bit 2 static priority for waves 0-3 (stagger)
+                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 7 : 7; }();
                 if (!attr3) {
                     hipError_t e = hipSuccess;
-                    const void* fns[4] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
+                    const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 2>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>)};
-                    for (int v = 0; v < 4 && e == hipSuccess; ++v)
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 5>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>)};
+                    for (int v = 0; v < 5 && e == hipSuccess; ++v)
                         e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
                 }
+#define DUDF_WG_GO(V) hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, V>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a)
                 switch (var) {
-                    case 0: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 0>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
-                    case 1: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 1>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
-                    case 2: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 2>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
-                    default: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 3>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a); break;
+                    case 0: DUDF_WG_GO(0); break;
+                    case 1: DUDF_WG_GO(1); break;
+                    case 3: DUDF_WG_GO(3); break;
+                    case 5: DUDF_WG_GO(5); break;
+                    default: DUDF_WG_GO(7); break;
                 }
+#undef DUDF_WG_GO
                 return (int)hipGetLastError();
             }
         }

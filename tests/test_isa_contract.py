@@ -57,7 +57,7 @@ def test_wgrad_register_staging_contract(tmp_path):
     behind hand-counted waits; no instruction may read or write such a register before its wait."""
     asm = str(tmp_path / "wgrad.s")
     emit_asm(os.path.join(REPO, "diffudf_amd", "csrc", "dudf_wgrad.hip"), asm)
-    for var in range(4):                  # plain / conflict-free producer lanes / interleaved split / both (the default)
+    for var in (0, 1, 3, 5, 7):           # bit 0 conflict-free producer lanes, bit 1 interleaved split, bit 2 priority stagger
         res = analyse_wgrad_presplit(asm, var)
         assert res["loads"] == 12 and res["carried"] == 12, (var, res)
         assert not res["bad"], (var, res["bad"][:5])
