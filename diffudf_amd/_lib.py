@@ -37,6 +37,7 @@ _CFG = ctypes.POINTER(NetCfg)
 _DBL = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = {
     "dudf_version": (ctypes.c_char_p, []),
+    "dudf_sweeps_bf16x6": (ctypes.c_int, [_CFG]),
     "dudf_theta_count": (ctypes.c_int64, [_CFG]),
     "dudf_workspace_bytes": (ctypes.c_size_t, [_CFG, ctypes.c_int64]),
     "dudf_workspace_bytes_hess": (ctypes.c_size_t, [_CFG, ctypes.c_int64, ctypes.c_int64]),

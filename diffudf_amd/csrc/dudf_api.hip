@@ -150,6 +150,11 @@ const char* dudf_version(void) {
            "Hessian quads, third-order jets, GPU sampler, ray marching)";
 }
 
+int dudf_sweeps_bf16x6(const dudf_net_cfg* cfg) {
+    if (!cfg) return 0;
+    return (use_bf16_sweeps() && dudf_sweep_bf16_supported(SWEEP_FWD, cfg->hidden, cfg->n_hidden_layers)) ? 1 : 0;
+}
+
 int64_t dudf_theta_count(const dudf_net_cfg* cfg) {
     DudfLayout lo;
     if (dudf_make_layout(cfg, 1, 0, &lo)) return -1;

@@ -55,6 +55,9 @@ struct GeoB {
 
 
 __device__ __forceinline__ f32x4 mfma_b(bf16x8 a, bf16x8 b, f32x4 c) {
+#if DUDF_SWEEP_DBG & 4
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c;
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned cvt_pk(f32x2 v) {              // one v_cvt_pk_bf16_f32: lo = bf16(v.x), hi = bf16(v.y)
@@ -87,6 +90,9 @@ template <int H>
 __device__ __forceinline__ void dma_issue(const char* __restrict__ chunk, unsigned lds_off, unsigned voff, int wave) {
     using G = GeoB<H>;
     static_assert(G::NDMA == 6 || G::NDMA == 3, "asm below is written for 3 or 6 pieces per wave");
+#if DUDF_SWEEP_DBG & 8
+    return;
+#endif
     const uint64_t g0 = (uint64_t)(size_t)chunk + (uint64_t)wave * (G::NDMA * G::FRAG);       // wave-uniform
     const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
     const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
@@ -249,6 +255,9 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             const int c = j * G::NKB + kb;
             const char* bp = lds + gc * G::CHUNKB + lane * 16;
             auto frag = [&](int T, int pc) -> bf16x8 {
+#if DUDF_SWEEP_DBG & 32
+                bf16x8 z; asm volatile("" : "=v"(z)); return z;
+#endif
                 return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
             };
             if constexpr (!HS) ops_cur = ops_n1;
@@ -298,9 +307,13 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             }
             bh = nh; bm = nm; bl = nl;
             gc = (gc + 1) % 3;
+#if !(DUDF_SWEEP_DBG & 8)
             if (more) dma_wait_b<2 * kYoung + G::NDMA>();               // chunk c+1 landed; c+2 and two steps' stash traffic stay in flight
             else dma_wait_b<0>();
+#endif
+#if !(DUDF_SWEEP_DBG & 16)
             __syncthreads();
+#endif
         }
     }
 

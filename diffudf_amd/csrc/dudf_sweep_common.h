@@ -21,6 +21,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 typedef float dudf_f2 __attribute__((ext_vector_type(2)));
 typedef int dudf_i2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2& c_out) {
+#if DUDF_SWEEP_DBG & 64
+    s_out = x; c_out = x * 0.5f; return;
+#endif
     const dudf_f2 k = {rintf(x.x * 0.636619772367581343f), rintf(x.y * 0.636619772367581343f)};
     dudf_f2 r = __builtin_elementwise_fma(-k, (dudf_f2)(1.57079637050628662109375f), x);
     r = __builtin_elementwise_fma(-k, (dudf_f2)(-4.37113900018624283e-8f), r);
@@ -49,8 +52,20 @@ __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2&
 #define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>(reinterpret_cast<char*>((arr) + (ub)) + (vo))
 #define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>((arr) + (ub)) + (vo))
 // the stash is a stream (written once, read once or twice, 14 GB per step): non-temporal accesses
+#ifndef DUDF_SWEEP_DBG
+#define DUDF_SWEEP_DBG 0    // timing experiments only (wrong results): 1 no stash stores, 2 no stash loads, 4 no MFMA (bf16 kernel),
+#endif                      // 8 no weight DMA, 16 no k-block barrier, 32 no LDS fragment reads, 64 no sin/cos
+#if DUDF_SWEEP_DBG & 1
+#define DUDF_ST(arr, ub, vo, val) asm volatile("" :: "v"((f32x4)(val)))
+#else
 #define DUDF_ST(arr, ub, vo, val) __builtin_nontemporal_store((f32x4)(val), DUDF_AT(arr, ub, vo))
+#endif
+#if DUDF_SWEEP_DBG & 2
+__device__ __forceinline__ f32x4 dudf_dbg_any() { f32x4 z; asm volatile("" : "=v"(z)); return z; }
+#define DUDF_LD(arr, ub, vo) dudf_dbg_any()
+#else
 #define DUDF_LD(arr, ub, vo) __builtin_nontemporal_load(DUDF_CAT(arr, ub, vo))
+#endif
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
 __device__ __forceinline__ float quad_bcast0(float v) {          // value of the quad's lane 0 (the value channel)

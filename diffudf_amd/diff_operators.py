@@ -13,6 +13,37 @@ from . import hip_ops
 from ._lib import DudfError
 
 
+class FieldTensor(torch.Tensor):
+    """What `SIREN.forward` returns as 'model_out' and what `gradient` / `compute_normals_and_cd` return: an ordinary
+    tensor that remembers WHICH field of the network it is (`_dudf_kind`: 'value', 'grad', 'eig_normal') and hands
+    that on — prefixed with 'from:' — to anything computed from it.  The reference's operators take (y, x) pairs of an
+    autograd graph; here the pair has to name a field the kernels can evaluate, and a tensor derived from one (a
+    squeezed output, but also a slice of a gradient) must not be mistaken for another."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        kind = None
+        for a in args:
+            k = getattr(a, "_dudf_kind", None) if isinstance(a, torch.Tensor) else None
+            if k is not None:
+                kind = k if k.startswith("from:") else "from:" + k
+                break
+        if kind is not None:
+            for o in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(o, FieldTensor) and getattr(o, "_dudf_kind", None) is None:
+                    o._dudf_kind = kind
+        return out
+
+
+def tag_field(t, kind, model_ref=None, coords=None):
+    t = t.as_subclass(FieldTensor)
+    t._dudf_kind = kind
+    if model_ref is not None:
+        t._dudf_src = (model_ref, coords)
+    return t
+
+
 def _source(y, x):
     """(model, coords) behind a reference-style (y, x) pair.  `y` carries the tag when it is exactly what `forward`
     returned; any tensor DERIVED from it (the reference's own `pred_sdf.squeeze(-1)`, src/loss_functions.py:141, a
@@ -33,16 +64,20 @@ def _source(y, x):
 
 
 def _kind(y, coords):
-    """What field of the network `y` is: tagged results keep their tag; an untagged tensor with one value per point
-    is the model output (or a view of it)."""
+    """What field of the network `y` is.  Tagged results keep their tag; a tensor computed FROM the model output that
+    still has one value per point (squeeze / reshape / view, e.g. reference src/loss_functions.py:141) is the model
+    output; everything else has no HIP path."""
     k = getattr(y, "_dudf_kind", None)
-    if k is not None:
-        return k
     n = coords.numel() // 3
-    if y.numel() == n:
+    if k in ("value", "grad", "eig_normal"):
+        return k
+    if k == "from:value" and y.numel() == n:
         return "value"
-    raise DudfError("this tensor is not a field the HIP path knows (model output, its gradient, or the eigen-normal "
-                    "field of compute_normals_and_cd); slices of a gradient have no HIP path — use hessian(y, x)")
+    if k is None:
+        raise DudfError("this tensor does not come from diffudf_amd.model.SIREN.forward (generic autograd graphs have no "
+                        "HIP path here)")
+    raise DudfError(f"no HIP path for a tensor derived from the '{k[5:]}' field (slices of a gradient: use hessian(y, x); "
+                    "arbitrary functions of the output: use fields())")
 
 
 def gradient(y, x, grad_outputs=None):
@@ -55,9 +90,8 @@ def gradient(y, x, grad_outputs=None):
     g = g.reshape(coords.shape)
     if grad_outputs is not None:
         g = g * grad_outputs.reshape(coords.shape[:-1] + (1,))
-    else:
-        g._dudf_kind = "grad"                          # divergence(gradient(y, x), x) finds its way (laplace)
-    return g
+        return tag_field(g, "from:grad")
+    return tag_field(g, "grad")                        # divergence(gradient(y, x), x) finds its way (laplace)
 
 
 def hessian(y, x):

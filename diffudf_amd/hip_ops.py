@@ -20,6 +20,12 @@ def make_cfg(hidden, w0=30.0, n_in=3, n_out=1):
     return NetCfg(3, len(hidden), int(hidden[0]), float(w0))
 
 
+def sweeps_on_bf16(hidden, layers, w0=30.0):
+    """True when this network's sweeps run on the bf16 matrix cores (bf16x6) rather than on the f32-input MFMA."""
+    cfg = NetCfg(3, int(layers), int(hidden), float(w0))
+    return bool(_lib.load().dudf_sweeps_bf16x6(ctypes.byref(cfg)))
+
+
 def theta_count(cfg):
     n = _lib.load().dudf_theta_count(ctypes.byref(cfg))
     if n < 0:

@@ -170,7 +170,8 @@ class SIREN(nn.Module):
             raise DudfError("HIP path is fp32; call model.float()")
         y = _SirenValue.apply(self, coords_org, *self.parameters())
         # lets diff_operators.gradient(y, x) find the network that produced y
-        y._dudf_src = (weakref.ref(self), coords_org)
+        from .diff_operators import tag_field
+        y = tag_field(y, "value", weakref.ref(self), coords_org)
         # ... and anything DERIVED from y (squeeze, reshape: Python attributes do not survive) through model_in
         coords_org._dudf_model = weakref.ref(self)          # (no self-reference: no cycle)
         return {"model_in": coords_org, "model_out": y}

@@ -24,8 +24,8 @@ def compute_normals_and_cd(inputs, outputs):
     _, _, _, _, V = hip_ops.query_frame(model.hip_cfg, model.flat_parameters(), x2)
     lead = coords.shape[:-1]
     normals = V[:, :, 2].reshape(lead + (3,))
-    normals._dudf_src = (weakref.ref(model), coords)          # compute_curvature(inputs, normals) finds its way back
-    normals._dudf_kind = "eig_normal"
+    from .diff_operators import tag_field
+    normals = tag_field(normals, "eig_normal", weakref.ref(model), coords)   # compute_curvature(inputs, normals) finds its way back
     return normals, V[:, :, :2].reshape(lead + (3, 2)).detach().cpu()
 
 

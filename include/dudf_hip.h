@@ -214,6 +214,9 @@ int dudf_profile_dump(char* buf, size_t buflen);
 
 /* library / build identification, host string */
 const char* dudf_version(void);
+/* 1 when the hidden-layer matmuls of this network's plain-column sweeps run on the bf16 matrix cores with the exact
+ * 3-way split (bf16x6, fp32-equivalent), 0 when they run on the f32-input MFMA (bench.py prices its roofline with it). */
+int dudf_sweeps_bf16x6(const dudf_net_cfg* cfg);
 
 #ifdef __cplusplus
 }

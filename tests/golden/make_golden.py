@@ -205,6 +205,35 @@ def make_g8():
     np.savez_compressed(os.path.join(HERE, "g8_operators.npz"), **out)
 
 
+def make_g9():
+    """G9: the field slice of reference generate_df.py:50-107 (`generate_df`; the script needs open3d, so its numpy/torch
+    lines are issued here around the REFERENCE `evaluate`, `normalize` and torch.linalg.eigh): sample plane, predicted
+    value, |grad f|, and the normal map before colouring.  48 x 48 samples, SIREN 8x256 from the synth generator."""
+    from src.util import normalize                                   # reference
+    out = {}
+    hid, W = [256] * 8, 48
+    P = synth.siren_params(hid, seed=123, dtype=np.float64)
+    model = ref_model(hid, P, torch.float32)
+    BORDES, EJEPLANO, OFFSETPLANO = [1, -1], [2, 1, 0], 0.0
+    ranges = np.linspace(BORDES[0], BORDES[1], W)
+    i_1, i_2 = np.meshgrid(ranges, ranges)
+    samples = np.concatenate(np.concatenate(np.array([np.expand_dims(i_1, 2), np.expand_dims(i_2, 2),
+                                                      np.expand_dims(np.ones_like(i_1) * OFFSETPLANO, 2)])[EJEPLANO], axis=2), axis=0)
+    gradients = np.zeros((W * W, 3)); hessians = np.zeros((W * W, 3, 3))
+    pred = evaluate(model, samples, device=torch.device("cpu"), gradients=gradients, hessians=hessians)
+    gnorm = np.linalg.norm(gradients, axis=1).reshape((-1, 1))
+    g = normalize(gradients)
+    lam, V = torch.linalg.eigh(torch.from_numpy(hessians))
+    pn = V[..., 2].numpy()
+    pn = np.where(np.sum(g * pn, axis=-1)[..., None] < 0, np.ones((len(pn), 1)) * -1, np.ones((len(pn), 1))) * pn
+    normals = np.where(np.concatenate([gnorm, gnorm, gnorm], axis=-1) < 0.04, pn, g)
+    normals = normals * np.hstack([np.ones((len(normals), 2)), np.sign(normals[:, 2]).reshape((len(normals), 1))])
+    out["width"] = np.array(W); out["samples"] = samples; out["pred_distances"] = pred; out["pred_grad_norm"] = gnorm
+    out["normals"] = normals; out["grad_map_u8"] = (((normals + 1) / 2).reshape(W, W, 3) * 255).astype(np.uint8)
+    out["hidden"] = np.array(hid); out["param_seed"] = np.array(123)
+    np.savez_compressed(os.path.join(HERE, "g9_slice.npz"), **out)
+
+
 def main():
     # ---- G1: tiny net, everything stored --------------------------------------------------
     out = {}
@@ -315,6 +344,7 @@ def main():
     make_g6()
     make_g7()
     make_g8()
+    make_g9()
     print("golden fixtures written to", HERE)
 
 
@@ -325,5 +355,7 @@ if __name__ == "__main__":
         make_g7()
     elif sys.argv[1:] == ["g8"]:
         make_g8()
+    elif sys.argv[1:] == ["g9"]:
+        make_g9()
     else:
         main()
