@@ -32,6 +32,11 @@ void dudf_prof_end(int slot, hipStream_t st) {
     g_prof_recs.push_back({slot, g_prof_open[slot], e1});
 }
 
+bool dudf_deterministic() {
+    static const bool on = [] { const char* e = getenv("DUDF_DETERMINISTIC"); return e && e[0] == '1'; }();
+    return on;
+}
+
 namespace {
 
 // DUDF_SWEEP=f32 keeps every sweep on the f32-input MFMA kernel (A/B testing); default: bf16x6 where it is built

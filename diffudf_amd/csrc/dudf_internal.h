@@ -162,6 +162,12 @@ int dudf_launch_make_x4_jet(const float* x, const float* V, int64_t n, int64_t n
 int dudf_launch_curvature(const float* yj, const float* lam, const float* V, int64_t n, float* out_mean,
                           float* out_gauss, float* out_shape, hipStream_t st);
 
+// DUDF_DETERMINISTIC=1 (read once): every cross-workgroup sum of the training path — loss terms, loss_s2 statistics, dW, db —
+// is formed by ONE workgroup per output element (a single block for the loss sums, one column split per weight tile,
+// one block for the thin layers), so repeated launches give bit-identical results.  A test mode: the weight-gradient
+// GEMM then runs on 7 CUs.
+bool dudf_deterministic();
+
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,
        PROF_WGRAD_SMALL, PROF_LOSS_FWD, PROF_LOSS_BWD, PROF_ADAM, PROF_OTHER, PROF_NSLOTS };

@@ -615,7 +615,7 @@ int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, c
     LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
     hipError_t e = hipMemsetAsync(a.acc, 0, 4 * sizeof(double), st);
     if (e != hipSuccess) return (int)e;
-    const int grid = grid_for(lo.n);
+    const int grid = dudf_deterministic() ? 1 : grid_for(lo.n);        // one block: one fixed summation order
     if (mode == DUDF_LOSS_S1) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_S1>, dim3(grid), dim3(256), 0, st, a);
     else if (mode == DUDF_LOSS_SIREN) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_SIREN>, dim3(grid), dim3(256), 0, st, a);
     else return DUDF_E_BADMODE;
@@ -643,7 +643,7 @@ int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, doub
     if (e != hipSuccess) return (int)e;
     const double w0[4] = {0, 0, 0, 0};
     LossArgs a = make_loss_args(lo, nullptr, sdf, 1, w0, 0.0, ws);
-    hipLaunchKernelGGL(s2_stats_kernel, dim3(grid_for(lo.n)), dim3(256), 0, st, a, stats);
+    hipLaunchKernelGGL(s2_stats_kernel, dim3(dudf_deterministic() ? 1 : grid_for(lo.n)), dim3(256), 0, st, a, stats);
     return (int)hipGetLastError();
 }
 

@@ -737,7 +737,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     const int tz = a.Hs / H, ntz = tz * tz;              // output tiles of a layer wider than the 256 x 256 tile
     int nsplit = 256 / (nl * ntz);                       // one resident workgroup per CU, a single round
     if (nsplit > a.steps_total) nsplit = a.steps_total;
-    if (nsplit < 1) nsplit = 1;
+    if (nsplit < 1 || dudf_deterministic()) nsplit = 1;      // deterministic: one workgroup per weight tile, one add per element
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_kernel<H>),
@@ -820,7 +820,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
-    s.pts_per_block = 1024;
+    s.pts_per_block = dudf_deterministic() ? (int)lo.ncols : 1024;
     const int grid = (int)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block);
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
     const int gy = (lo.H / 4 >= 16) ? 4 : 1;

@@ -279,3 +279,65 @@ np.savez(sys.argv[1], terms=terms.cpu().numpy(), g=g.cpu().numpy(), f=f.cpu().nu
         assert rel(outs[tag]["terms"], np.array(list(terms.values()))) < 1e-5, tag
     assert rel(outs["bf16"]["f"], outs["f32"]["f"]) < 2e-6
     assert rel(outs["bf16"]["g"], outs["f32"]["g"]) < 5e-6
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """DUDF_DETERMINISTIC=1 (SURVEY.md §5 'race detection' row): every cross-workgroup sum has one owner, so loss terms,
+    loss_s2 statistics and d(theta) are BIT-IDENTICAL across launches — for the Eikonal loss, the Hessian loss (quad
+    columns) and stage 2, at a batch that spans several workgroup passes, and for a two-shard accumulation.  The
+    default build sums partial tiles with float atomics: its launches agree to rounding only (checked too, so that the
+    test would notice if the switch stopped doing anything).  What cannot be bit-identical in fp32 is 1-vs-N shards: the
+    shards' partial sums are rounded before they are added (they agree to ~1e-7, tests/test_multirank_gpu.py)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from diffudf_amd import hip_ops as hip, synth
+hid = [256] * 8
+n = 5000
+th = torch.from_numpy(synth.flatten_params(synth.siren_params(hid, seed=123))).cuda()
+x, nrm, sdf = [torch.from_numpy(a).cuda() for a in synth.training_batch(n, seed=9, step=0)]
+sdf = sdf.reshape(-1)
+cfg = hip.make_cfg(hid)
+ones = torch.ones(4, device="cuda")
+out = {}
+for rep in range(3):
+    ws = hip.workspace_for(cfg, n, th.device)
+    t = hip.loss_forward(cfg, 0, th, x, nrm, sdf, n, [1e4, 1e4, 0.0, 1e3], 100.0, ws)
+    g = hip.loss_backward(cfg, 0, th, x, nrm, sdf, n, [1e4, 1e4, 0.0, 1e3], 100.0, ones, None, ws)
+    out["eik_t%%d" %% rep] = t.cpu().numpy(); out["eik_g%%d" %% rep] = g.cpu().numpy()
+    nh = int((sdf == 0).sum())
+    wsh = hip.workspace_for(cfg, n, th.device, n_hess=nh)
+    t = hip.loss_forward(cfg, 0, th, x, nrm, sdf, n, [1e4, 1e4, 1e4, 1e3], 100.0, wsh, n_hess=nh)
+    g = hip.loss_backward(cfg, 0, th, x, nrm, sdf, n, [1e4, 1e4, 1e4, 1e3], 100.0, ones, None, wsh, n_hess=nh)
+    out["full_t%%d" %% rep] = t.cpu().numpy(); out["full_g%%d" %% rep] = g.cpu().numpy()
+    ws = hip.workspace_for(cfg, n, th.device)
+    st = hip.s2_forward_stats(cfg, th, x, sdf, ws)
+    g = hip.loss_backward(cfg, 1, th, x, nrm, sdf, n, [1e5, 1e5], 100.0, ones, st, ws)
+    out["s2_t%%d" %% rep] = st.cpu().numpy(); out["s2_g%%d" %% rep] = g.cpu().numpy()
+    # two uneven shards of the same batch accumulated into one d(theta) (accumulate = 1), in a fixed order
+    acc = torch.zeros_like(th)
+    for a, b in ((0, 1777), (1777, n)):
+        xs, ns, ss = x[a:b].contiguous(), nrm[a:b].contiguous(), sdf[a:b].contiguous()
+        w2 = hip.workspace_for(cfg, b - a, th.device)
+        hip.loss_forward(cfg, 0, th, xs, ns, ss, n, [1e4, 1e4, 0.0, 1e3], 100.0, w2)
+        hip.loss_backward(cfg, 0, th, xs, ns, ss, n, [1e4, 1e4, 0.0, 1e3], 100.0, ones, None, w2, dtheta=acc, accumulate=True)
+    out["shard_g%%d" %% rep] = acc.cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("det", {"DUDF_DETERMINISTIC": "1"}), ("atomic", {})):
+            path = os.path.join(td, tag + ".npz")
+            e = dict(os.environ); e.update(env)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=900)
+            res[tag] = dict(np.load(path))
+    d, a = res["det"], res["atomic"]
+    for k in ("eik_t", "eik_g", "full_t", "full_g", "s2_t", "s2_g", "shard_g"):
+        assert np.array_equal(d[k + "0"], d[k + "1"]) and np.array_equal(d[k + "0"], d[k + "2"]), k   # bit for bit
+        assert rel(a[k + "0"], d[k + "0"]) < (5e-5 if k.startswith("full") else 2e-6), k              # same numbers
+    assert rel(d["shard_g0"], d["eik_g0"]) < 2e-6                 # shards: equal to rounding, not to the bit
+    moved = sum(not np.array_equal(a[k + "0"], a[k + "1"]) for k in ("eik_g", "full_g", "s2_g", "shard_g"))
+    print("deterministic mode: all bit-identical; default mode: %d of 4 gradients differ in the last bits between launches" % moved)
