@@ -763,9 +763,13 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
             if (!per_wave) {
                 static bool attr3 = false;
                 const size_t smem_p = 2 * 2 * 3 * (size_t)(H / 32) * 2 * (32 * 16 + 16);   // 2 buffers x (X | Y) x 3 pieces x blocks
+                if ((int64_t)(a.Hs / 4) * a.np * 16 >= (1ll << 32)) {       // beyond the 32-bit lane byte offsets of the staging loads:
+                    hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_bf, st, a);   // per-wave split
+                    return (int)hipGetLastError();
+                }
                 // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7} (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split,
                 // bit 2 static priority for waves 0-3 (stagger)
-                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 7 : 7; }();
+                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 7 : 3; }();
                 if (!attr3) {
                     hipError_t e = hipSuccess;
                     const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
@@ -784,7 +788,8 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     case 1: DUDF_WG_GO(1); break;
                     case 3: DUDF_WG_GO(3); break;
                     case 5: DUDF_WG_GO(5); break;
-                    default: DUDF_WG_GO(7); break;
+                    case 7: DUDF_WG_GO(7); break;
+                    default: DUDF_WG_GO(3); break;
                 }
 #undef DUDF_WG_GO
                 return (int)hipGetLastError();

@@ -98,14 +98,17 @@ def _vregs(tok):
     return out
 
 
-def analyse_wgrad_presplit(asm_path, var=0):
+def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
     """wgrad_hidden_bf16p_kernel<256> stages the stash through REGISTERS with inline-asm loads and hand-counted vmcnt
     waits inside its steady-state loop (hipcc does not know those registers are in flight).  Finds that loop (the
     self-looping basic block that holds the MFMAs and the asm loads), replays it twice with a FIFO of the loads — the
     second pass starts with what the first left in flight — and returns the instructions that touch a destination
     register of a load still in flight (must be none), the loads per pass and the loads in flight across the back edge."""
     txt = open(asm_path).read()
-    m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
+    if kernel == "q":          # the fragment-prefetching kernel: two register sets (8 loads) per pass of its two-stage loop
+        m = re.search(r"^(_ZN\w*wgrad_hidden_bf16q_kernelILi256E\w*):", txt, re.M)
+    else:
+        m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
     body = txt[m.end():txt.index("s_endpgm", m.end())].split("\n")
     blocks, cur, name = [], [], "entry"
     for ln in body:
@@ -116,7 +119,7 @@ def analyse_wgrad_presplit(asm_path, var=0):
         else:
             cur.append(t)
     blocks.append((name, cur))
-    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= 100
+    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= 90
            and any(x.startswith("global_load_dwordx4") for x in b)]
     assert len(hot) == 1, [n for n, _ in hot]
     name, blk = hot[0]

@@ -62,3 +62,4 @@ def test_wgrad_register_staging_contract(tmp_path):
         assert res["loads"] == 12 and res["carried"] == 12, (var, res)
         assert not res["bad"], (var, res["bad"][:5])
         assert res["scratch"] == 0, var
+
