@@ -224,7 +224,6 @@ struct CurvLayout { DudfLayout q; int64_t npj, o_lam, o_V, o_x4, o_y; size_t tot
 int make_curv_layout(const dudf_net_cfg* cfg, int64_t n, CurvLayout* cl) {
     int rc = dudf_make_layout(cfg, n, n, &cl->q, 1);
     if (rc) return rc;
-    if (cl->q.H > 256) return DUDF_E_UNSUPPORTED;
     cl->npj = (16 * n + DUDF_TILE_PTS - 1) / DUDF_TILE_PTS * DUDF_TILE_PTS;
     if (cl->npj == 0) cl->npj = DUDF_TILE_PTS;
     if (cl->npj > (1ll << 25)) return DUDF_E_BADCFG;

@@ -335,21 +335,20 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
             break;
         // Hessian-quad variants: not built for H = 512 (hipcc 7.2 emits illegal AGPR operands for them at 512 registers)
         case SWEEP_FWD_H:
-            if constexpr (H > 256) return DUDF_E_UNSUPPORTED;
-            else { if (!a.store_s) return DUDF_E_BADMODE; DUDF_GO(SWEEP_FWD_H, 1); }
+            if (!a.store_s) return DUDF_E_BADMODE;
+            DUDF_GO(SWEEP_FWD_H, 1);
             break;
         case SWEEP_REV_H:
-            if constexpr (H > 256) return DUDF_E_UNSUPPORTED;
-            else { if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0); }
+            if (a.train) DUDF_GO(SWEEP_REV_H, 1); else DUDF_GO(SWEEP_REV_H, 0);
             break;
         case SWEEP_ADJ_FWD_H:
-            if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_ADJ_FWD_H, 0);
+            DUDF_GO(SWEEP_ADJ_FWD_H, 0);
             break;
         case SWEEP_ADJ_REV_H:
-            if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_ADJ_REV_H, 0);
+            DUDF_GO(SWEEP_ADJ_REV_H, 0);
             break;
         case SWEEP_FWD_J:
-            if constexpr (H > 256) return DUDF_E_UNSUPPORTED; else DUDF_GO(SWEEP_FWD_J, 0);
+            DUDF_GO(SWEEP_FWD_J, 0);
             break;
         default: return DUDF_E_BADMODE;
     }

@@ -68,11 +68,17 @@ __device__ __forceinline__ f32x4 dudf_dbg_any() { f32x4 z; asm volatile("" : "=v
 #endif
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
+// (the empty asm pins the DPP source to an ARCHITECTURAL vector register: in the 512-register kernels of the 512-wide
+//  layers hipcc 7.2 keeps values in accumulation registers and then emits DPP moves that read them, which the assembler
+//  rejects — "explicit register staging")
 __device__ __forceinline__ float quad_bcast0(float v) {          // value of the quad's lane 0 (the value channel)
+    asm volatile("" : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x00, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float quad_sum(float v) {             // sum over the quad, in every lane
+    asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    asm volatile("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
     return v;
 }

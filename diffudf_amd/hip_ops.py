@@ -159,7 +159,7 @@ def query_curvature(cfg, theta, x, want_shape=False, chunk=65536):
     m = min(max(n, 1), int(chunk))
     nbytes = int(lib.dudf_workspace_bytes_curvature(ctypes.byref(cfg), m))
     if nbytes == 0:
-        _lib.check(-4 if cfg.hidden > 256 else -1, "dudf_workspace_bytes_curvature")
+        _lib.check(-1, "dudf_workspace_bytes_curvature")
     buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     for s in range(0, n, m):
         e = min(s + m, n)

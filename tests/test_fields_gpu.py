@@ -193,3 +193,24 @@ def test_divergence_laplace_and_derived_outputs(golden_dir):
         assert rel(dn * sgn, 2.0 * G6[f"{tag}_f64_mean"]) < 1e-4           # trace of the shape operator = 2 x mean curvature
         with pytest.raises(Exception):
             dif.gradient(g[..., 0], xin)                                   # slices of a gradient: documented as unsupported
+
+
+def test_curvature_and_frame_at_width_512():
+    """BASELINE config 3's width: Hessian quads, eigen-frame and third-order jets at H = 512 (f32-input MFMA kernel),
+    against the oracle's Hessian and third derivatives."""
+    from diffudf_amd import hip_ops as hip
+    model, P = make_model([512] * 3, 9)
+    x = (synth.uniform01(5, 91, 0, 3 * 96).reshape(96, 3) * 1.8 - 0.9).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    f, g, H, lam, V = hip.query_frame(model.hip_cfg, model.flat_parameters(), xt)
+    yo, go, Ho = oracle_fgh(P, x.astype(np.float64))
+    assert rel(f.cpu().numpy(), yo) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5 and rel(H.cpu().numpy(), Ho) < 2e-5
+    no, _, mo, gaus_o, Jo = O.curvatures(P, x.astype(np.float64))
+    lam3, V3, mean, gauss, J = hip.query_curvature(model.hip_cfg, model.flat_parameters(), xt, want_shape=True)
+    lam_o = np.linalg.eigvalsh(np.tril(Ho) + np.transpose(np.tril(Ho, -1), (0, 2, 1)))
+    gap = np.minimum(lam_o[:, 2] - lam_o[:, 1], lam_o[:, 1] - lam_o[:, 0]) / (lam_o[:, 2] - lam_o[:, 0])
+    ok = gap > 0.05
+    sgn = np.sign((V3.cpu().numpy()[:, :, 2] * no).sum(1))
+    assert ok.sum() > 40
+    assert rel((J.cpu().numpy() * sgn[:, None, None])[ok], Jo[ok]) < 2e-4
+    assert rel((mean.cpu().numpy() * sgn)[ok], mo[ok]) < 2e-4

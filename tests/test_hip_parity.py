@@ -130,7 +130,7 @@ TOL_H = 2e-5
 W_S1FULL = [1e4, 1e4, 1e4, 1e3]
 
 
-@pytest.mark.parametrize("hidden,n,seed", NETS)
+@pytest.mark.parametrize("hidden,n,seed", NETS_WIDE)
 def test_query_hessian(hip, hidden, n, seed):
     P, theta, x, _, _ = setup(hidden, n, seed)
     cfg = hip.make_cfg(hidden)
@@ -142,7 +142,7 @@ def test_query_hessian(hip, hidden, n, seed):
     assert ef < TOL_F and eg < TOL_G and eh < TOL_H
 
 
-@pytest.mark.parametrize("hidden,n,seed", NETS)
+@pytest.mark.parametrize("hidden,n,seed", NETS_WIDE)
 def test_loss_s1_with_hessian_term(hip, hidden, n, seed):
     """The full reference training loss (configs/train_cfg.json weights): Hessian + eigh + its backward."""
     P, theta, x, nrm, sdf = setup(hidden, n, seed)
@@ -233,9 +233,8 @@ def test_unsupported_configs_fail_loudly(hip):
         hip.make_cfg([64, 32])
     with pytest.raises(_lib.DudfError):
         hip.query(hip.make_cfg([48, 48]), th, z)
-    cfg5 = hip.make_cfg([512] * 2)                  # Hessian path is not built for H = 512
-    with pytest.raises(_lib.DudfError):
-        hip.query_hessian(cfg5, torch.zeros(hip.theta_count(cfg5), device="cuda"), z)
+    with pytest.raises(_lib.DudfError):      # widths beyond the built set
+        hip.query_hessian(hip.make_cfg([1024] * 2), torch.zeros(8, device="cuda"), z)
 
 
 def test_f32_and_bf16x6_sweeps_agree():
