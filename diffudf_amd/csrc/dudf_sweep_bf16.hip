@@ -31,6 +31,7 @@
 //     the f32 kernel's 64-column workgroups would be bound by L2 -> LDS weight traffic, not by the matrix cores.
 //   * the first layer (K = 3+1) and the output / df/dx matmuls stay on the fp32 MFMA.
 #include "dudf_sweep_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -457,9 +458,273 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+
+// ====================================================================================================================
+// 512-wide layers (BASELINE.json configs[2]: SIREN 8x512), plain columns, training variants.
+// The scheme above keeps this layer's AND the previous layer's accumulators in registers (2 x NT x 4): at H = 512 that
+// is 256 registers before anything else, i.e. one wave per SIMD and 64-column workgroups, which the weight stream cannot
+// feed.  Here a wave keeps only THIS layer's 32 accumulator tiles (128 registers, two waves per SIMD, 128-column
+// workgroups as above) and the previous layer's outputs travel through the stash arrays the sweep writes anyway:
+//   * when a layer's accumulators are final its elementwise tails run in one burst (same `epilogue` as everywhere: bias,
+//     sin/cos or adjoint formulas, stash stores) — the post-tail value of every tile is exactly what one of those stores
+//     leaves behind (forward: h_l in S; reverse: q_l in Q; adjoint forward: A_l; adjoint reverse: zbar_l in Z);
+//   * the next layer reads its B operand back, one k-block (two 16-byte loads per lane) ahead of its use — this wave's
+//     own 2 KB per column, written a moment ago — splits it into the three bf16 pieces, and uses it for the 32 output
+//     tiles in two half-steps of 16 tiles: a weight chunk stays 48 KiB ([k-block][half]: the image of a k-block is
+//     [tile][piece], so a half is contiguous) and the three-buffer LDS-DMA stream is the one above;
+//   * the read-back loads are inline asm like the DMA: inside the k-loop the compiler sees no vector-memory operation,
+//     every wait is hand-counted (derivation at the waits); around a tail burst everything is drained once per layer.
+// Cost against the register-resident scheme: one more stash unit READ per layer and sweep (largely served by L2 / the
+// Infinity Cache: it is the unit just written), and the burst is not overlapped with this wave's own MFMAs.
+template <int SW> struct WideIn;                        // which stash array carries the post-tail values of sweep SW
+template <> struct WideIn<SWEEP_FWD> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.S; } };
+template <> struct WideIn<SWEEP_REV> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.Q; } };
+template <> struct WideIn<SWEEP_ADJ_FWD> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.A; } };
+template <> struct WideIn<SWEEP_ADJ_REV> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.Z; } };
+
+struct GeoW {
+    static constexpr int H = 512, NT = 32, NKB = 16, FRAG = 1024;
+    static constexpr int HALFT = 16;                    // tiles per half-step
+    static constexpr int CHUNKB = HALFT * 3 * FRAG;     // 48 KiB: one (k-block, half) of a matrix
+    static constexpr int IMGB = NKB * 2 * CHUNKB;       // one matrix (= GeoB<512>::IMGB)
+    static constexpr int NDMA = HALFT * 3 / NWB;        // 6 LDS-DMA wave-instructions per wave and chunk
+    static constexpr int NTHR = 64 * NWB;
+};
+
+template <int SW, int FL>
+__device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
+    using G = GeoW;
+    constexpr int H = G::H;
+    static_assert(SW <= SWEEP_ADJ_REV, "plain columns only");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int nhid = a.L - 1;
+    constexpr bool kFwdDir = (SW == SWEEP_FWD || SW == SWEEP_ADJ_FWD);
+    const int64_t p = (int64_t)(g_first + wave) * 16 + li;
+    auto image = [&](int j) -> const char* {
+        return kFwdDir ? a.wimg_f + (size_t)j * G::IMGB : a.wimg_t + (size_t)(nhid - 1 - j) * G::IMGB;
+    };
+    auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
+    auto bias_ptr = [&](int layer) -> const float* {
+        return layer == 0 ? a.theta + 3 * H : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;
+    };
+    auto stash_base = [&](int layer, int T) -> int64_t {
+        const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);
+    const int total2 = nhid * G::NKB * 2;
+    auto chunk_src = [&](int c2) -> const char* {       // c2 = (matrix, k-block, half), wave-uniform
+        const int j = c2 / (G::NKB * 2);
+        return image(j) + (size_t)(c2 - j * G::NKB * 2) * G::CHUNKB;
+    };
+    auto dma = [&](int c2, unsigned buf) {
+        // GeoB<256> has the same chunk geometry (16 tiles x 3 pieces, 6 pieces per wave): reuse its issue code
+        dma_issue<256>(chunk_src(c2), (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + buf * G::CHUNKB,
+                       (unsigned)lane * 16u, wave);
+    };
+    __syncthreads();                                   // every wave is past its last LDS read of the previous pass
+    dma(0, gc);
+    dma(1, (gc + 1) % 3);
+    if (wave >= nact) {                                // idle waves of a partial pass: same DMA pieces, same barriers
+        dma_wait_b<0>();
+        __syncthreads();
+        for (int j = 0; j < nhid; ++j) {
+            for (int hs = 0; hs < G::NKB * 2; ++hs) {
+                const int c2 = j * G::NKB * 2 + hs;
+                const bool more = c2 + 2 < total2;
+                if (more) dma(c2 + 2, (gc + 2) % 3);
+                gc = (gc + 1) % 3;
+                if (more) dma_wait_b<G::NDMA>(); else dma_wait_b<0>();
+                __syncthreads();
+            }
+            dma_wait_b<0>();
+            __syncthreads();                           // the barrier behind the active waves' tail burst
+        }
+        return;
+    }
+
+    f32x4 acc[G::NT];
+    float part = 0.f;                                  // forward: y partial sums; reverse: df/dx accumulator
+    f32x4 accg = {0, 0, 0, 0};
+    // ---- the elementwise tails of all 32 tiles of `layer` (operands one pair ahead), stash stores, output stage ----
+    auto tail_burst = [&](int layer, bool last) {
+        f32x4 o1[2], o2[2], o3[2], bs[2];
+        auto ld = [&](int T, int s) {
+            epilogue_loads<SW, FL>(a, stash_base(layer, T), vo, o1[s], o2[s], o3[s]);
+            if constexpr (SW == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int T = 0; T < G::NT; ++T) {
+            const int s = T & 1;
+            if (T + 1 < G::NT) ld(T + 1, s ^ 1);
+            f32x4 z = acc[T];
+            if constexpr (SW == SWEEP_FWD) z += bs[s];
+            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, true);
+            if (last) {
+                if constexpr (SW == SWEEP_FWD) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q);
+                    part += e[0] * wv[0] + e[1] * wv[1] + e[2] * wv[2] + e[3] * wv[3];
+                } else if constexpr (SW == SWEEP_REV) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w1t16 + li * H + 16 * T + 4 * q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accg = mfma16(wv[t], e[t], accg);
+                }
+            }
+            acc[T] = f32x4{0, 0, 0, 0};
+        }
+    };
+    // ---- first layer (fp32, K = 3): pre-activations / incoming adjoints of the 32 tiles, then their tails ----
+    {
+        float b = 0.f, yb = 1.f;
+        if constexpr (SW == SWEEP_FWD) b = (q < 3) ? a.x4[p * 4 + q] : 0.f;
+        if constexpr (SW == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;
+        if constexpr (SW == SWEEP_ADJ_REV) yb = a.ybar[p];
+#pragma unroll
+        for (int T = 0; T < G::NT; ++T) {
+            if constexpr (kFwdDir) acc[T] = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
+            else acc[T] = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
+        }
+        tail_burst(in_layer(0), false);
+    }
+    dma_wait_b<0>();                                   // chunks 0 and 1, and the burst's stores (read back below)
+    __syncthreads();
+
+    // read-back of the post-tail values of tiles 2kb, 2kb+1 of `layer`: two asm loads, scalar base + lane offset
+    auto ld_in = [&](int layer, int kb, f32x4& x0, f32x4& x1) {
+        const float* b0 = WideIn<SW>::arr(a) + stash_base(layer, 2 * kb);
+        const float* b1 = b0 + 16 * a.np;              // next tile: 16 feature rows further (stash_base is linear in T)
+        const uint64_t g0 = (uint64_t)(size_t)b0, g1 = (uint64_t)(size_t)b1;
+        // (readfirstlane returns int: go through unsigned, or a low word with its top bit set sign-extends into the high word)
+        const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)g0), h0 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
+        const unsigned l1 = __builtin_amdgcn_readfirstlane((unsigned)g1), h1 = __builtin_amdgcn_readfirstlane((unsigned)(g1 >> 32));
+        const uint64_t s0 = ((uint64_t)h0 << 32) | l0, s1 = ((uint64_t)h1 << 32) | l1;
+        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %4"
+                     : "=&v"(x0), "=&v"(x1) : "v"(vo), "s"(s0), "s"(s1) : "memory");
+    };
+    u32x4 bh, bm, bl;
+    for (int j = 0; j < nhid; ++j) {
+        const int lin = in_layer(j);
+        // read-back registers: `xa` carries the even k-blocks, `xb` the odd ones — the loop is unrolled by two so that a set
+        // is never copied while its asm loads are in flight (a rolled loop would rotate them with v_mov at the back edge)
+        f32x4 xa0, xa1, xb0, xb1;
+        ld_in(lin, 0, xa0, xa1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa0), "+v"(xa1));      // k-block 0: nothing to overlap it with yet
+        auto kstep = [&](int kb, f32x4& c0, f32x4& c1, f32x4& n0, f32x4& n1, auto steady) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c2 = (j * G::NKB + kb) * 2 + h;
+                const bool more = decltype(steady)::value || c2 + 2 < total2;    // compile-time in the steady loop: one basic block
+                if (h == 0) {
+                    // the read-back of this k-block was issued one k-block ago; younger than it: the 6 DMA pieces of the
+                    // half-step in between
+                    asm volatile("s_waitcnt vmcnt(6)" : "+v"(c0), "+v"(c1));
+                    split8(c0, c1, bh, bm, bl);
+                }
+                if (more) dma(c2 + 2, (gc + 2) % 3);
+                if (h == 0) ld_in(lin, kb + 1 < G::NKB ? kb + 1 : kb, n0, n1);   // the last one re-reads its own: uniform counts
+                __builtin_amdgcn_sched_barrier(0);
+                const char* bp = lds + gc * G::CHUNKB + lane * 16;
+                auto frag = [&](int T, int pc) -> bf16x8 {
+                    return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
+                };
+                bf16x8 an[2][3] = {{frag(0, 0), frag(0, 1), frag(0, 2)}, {frag(1, 0), frag(1, 1), frag(1, 2)}};
+#pragma unroll
+                for (int T = 0; T < G::HALFT; ++T) {
+                    const bf16x8 ah = an[T & 1][0], am = an[T & 1][1], al = an[T & 1][2];
+                    if (T + 2 < G::HALFT) {
+                        an[T & 1][0] = frag(T + 2, 0); an[T & 1][1] = frag(T + 2, 1); an[T & 1][2] = frag(T + 2, 2);
+                        __builtin_amdgcn_sched_barrier(0x76);
+                    }
+                    f32x4 cc = acc[G::HALFT * h + T];
+                    cc = mfma_b(am, as_bf(bm), cc);             // smallest terms first
+                    cc = mfma_b(al, as_bf(bh), cc);
+                    cc = mfma_b(ah, as_bf(bl), cc);
+                    cc = mfma_b(am, as_bf(bh), cc);
+                    cc = mfma_b(ah, as_bf(bm), cc);
+                    cc = mfma_b(ah, as_bf(bh), cc);
+                    acc[G::HALFT * h + T] = cc;
+                }
+                gc = (gc + 1) % 3;
+                // chunk c2+1 has landed.  Issued after its DMA: h == 0: [this step: 6 DMA + 2 read-back]; h == 1: [previous
+                // step: 2 read-back] + [this step: 6 DMA]  ->  8 younger operations either way
+                if (more) dma_wait_b<8>(); else dma_wait_b<0>();
+                __syncthreads();
+            }
+        };
+        const int kb_steady = (j + 1 == nhid) ? G::NKB - 2 : G::NKB;   // the stream's last two half-chunks have no successor
+#pragma unroll 1                                        // 384 MFMAs per iteration: the body stays inside the instruction cache
+        for (int kb = 0; kb < kb_steady; kb += 2) {
+            kstep(kb, xa0, xa1, xb0, xb1, std::true_type{});
+            kstep(kb + 1, xb0, xb1, xa0, xa1, std::true_type{});
+        }
+        if (j + 1 == nhid) {
+            kstep(G::NKB - 2, xa0, xa1, xb0, xb1, std::false_type{});
+            kstep(G::NKB - 1, xb0, xb1, xa0, xa1, std::false_type{});
+        }
+        // the last k-block's (dummy) read-back is still in flight and nothing will consume it: keep its registers until it
+        // has landed, or hipcc hands them to the burst below while the load is still writing them
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa0), "+v"(xa1), "+v"(xb0), "+v"(xb1));
+        tail_burst(in_layer(j + 1), j + 1 == nhid);
+        dma_wait_b<0>();
+        __syncthreads();
+    }
+    if constexpr (SW == SWEEP_FWD) {
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        part += a.theta[a.off_bo];
+        if (q == 0) a.y[p] = part;
+    } else if constexpr (SW == SWEEP_REV) {
+        if (q == 0) *reinterpret_cast<f32x4*>(a.g + p * 4) = f32x4{accg[0], accg[1], accg[2], 0.f};
+    }
+}
+
+template <int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_w[];
+    unsigned gc = 0;
+    const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
+    const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
+    for (int g = g0; g < g1; g += NWB)
+        sweep_tile_w<SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_w, gc);
+}
+
+int launch_w(int which, const SweepArgs& a, hipStream_t st) {
+    using G = GeoW;
+    const size_t smem = 3 * G::CHUNKB;
+    if (a.ntiles <= 0) return 0;
+    const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;
+    const int grid = ntb < 256 ? ntb : 256;
+    hipError_t e = hipSuccess;
+#define DUDF_GO_W(SW, FL)                                                                                   \
+    do {                                                                                                    \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_w_kernel<SW, FL>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
+            if (e != hipSuccess) return (int)e;                                                             \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((sweep_w_kernel<SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);               \
+    } while (0)
+    switch (which) {                                    // training variants only: queries at this width stay on the f32 kernel
+        case SWEEP_FWD: if (a.store_s && a.store_c) DUDF_GO_W(SWEEP_FWD, 3); else return DUDF_E_UNSUPPORTED; break;
+        case SWEEP_REV: if (a.train) DUDF_GO_W(SWEEP_REV, 1); else return DUDF_E_UNSUPPORTED; break;
+        case SWEEP_ADJ_FWD: DUDF_GO_W(SWEEP_ADJ_FWD, 0); break;
+        case SWEEP_ADJ_REV: if (a.have_e) DUDF_GO_W(SWEEP_ADJ_REV, 1); else DUDF_GO_W(SWEEP_ADJ_REV, 0); break;
+        default: return DUDF_E_UNSUPPORTED;
+    }
+#undef DUDF_GO_W
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
+    if (H == 512) return L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV;      // plain columns (training variants)
     return (H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
 }
 
@@ -468,6 +733,7 @@ int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st)
     switch (H) {
         case 256: return launch_b<256>(which, a, st);
         case 128: return launch_b<128>(which, a, st);
+        case 512: return launch_w(which, a, st);
         default: return DUDF_E_UNSUPPORTED;
     }
 }
@@ -490,5 +756,6 @@ int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, h
     DudfProfScope prof(PROF_PACK, st);
     if (lo.H == 256) return pack_b<256>(lo, theta, ws, st);
     if (lo.H == 128) return pack_b<128>(lo, theta, ws, st);
+    if (lo.H == 512) return pack_b<512>(lo, theta, ws, st);
     return 0;
 }
