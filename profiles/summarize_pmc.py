@@ -63,6 +63,14 @@ def main():
         out[k] = {c: (round(x, 3) if isinstance(x, float) else x) for c, x in m.items()}
     here = os.path.dirname(os.path.abspath(__file__))
     json.dump(out, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    build = None
+    try:                                                  # which build the bytes belong to (bench.py reports it with them)
+        import subprocess
+        build = subprocess.check_output(["git", "-C", here, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        pass
+    traffic["_meta"] = {"summary": f"profiles/{tag}_pmc_summary.json", "build": build,
+                        "workload": "python bench.py --steps 3 --warmup 1 (8x256, 100 000 points, Eikonal loss_s1)"}
     json.dump(traffic, open(os.path.join(here, "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
     for k, m in out.items():
         print(k, {c: m[c] for c in ("duration_us", "clock_ghz", "hbm_read_bytes", "hbm_write_bytes") if c in m})

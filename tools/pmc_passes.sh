@@ -22,6 +22,6 @@ fi
 i=0
 for C in "${CSETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_${SET}_$i -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${SET}_$i.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_${SET}_$i -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 > $R/gpurun_out/pmc_${SET}_$i.log 2>&1
   grep -c . $R/gpurun_out/pmc_${SET}_$i/pmc_counter_collection.csv || grep -i 'unable' $R/gpurun_out/pmc_${SET}_$i.log | cut -c1-200
 done
