@@ -42,6 +42,31 @@ def main():
     print(json.dumps({"metric": "grid field query points/sec (value + df/dx + inv_tanh + normalise)", "value": N ** 3 / dt,
                       "unit": "points/s", "grid": N, "seconds": dt, "tflops_fp32_mfma": 2 * F0 * N ** 3 / dt / 1e12,
                       "config": "BASELINE configs[4]: src/render_mc.py extract_fields field part"}))
+    # config 5, second half: CAP-UDF extraction (reference src/render_mc.py:201-256) consuming the fields ON THE DEVICE.  A
+    # random-init SIREN has no thin zero shell, so besides the network's own field (few or no active cells: the cost of the
+    # scan) an analytic wavy-sheet UDF of the same shape is extracted (a surface's worth of active cells).
+    from diffudf_amd.render_mc import extract_mesh_CAP  # noqa: F401  (the mirror; timed below through hip_ops to stay on the device)
+    ax = torch.linspace(-1.0, 1.0, N, device="cuda")
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    hh = Z - 0.15 * torch.sin(3.0 * X) * torch.cos(2.0 * Y)
+    gzx, gzy = -0.45 * torch.cos(3.0 * X) * torch.cos(2.0 * Y), 0.30 * torch.sin(3.0 * X) * torch.sin(2.0 * Y)
+    nrm = torch.sqrt(gzx * gzx + gzy * gzy + 1.0)
+    sd = hh / nrm
+    ndf_a = sd.abs().contiguous()
+    vec_a = (-torch.sign(sd)[..., None] * torch.stack([gzx, gzy, torch.ones_like(gzx)], -1) / nrm[..., None]).contiguous()
+    del X, Y, Z, hh, gzx, gzy, nrm, sd
+    for tag, (d_, v_) in (("network field", (df, vecs)), ("analytic sheet", (ndf_a, vec_a))):
+        hip_ops.capudf_extract(d_, v_)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        vv, ff = hip_ops.capudf_extract(d_, v_)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(json.dumps({"metric": f"CAP-UDF cell extraction cells/sec ({tag}: active-cell scan + sign by gradient + per-cell "
+                                    "marching cubes + ordered compaction, fields resident on the device)",
+                          "value": (N - 1) ** 3 / dt, "unit": "cells/s", "grid": N, "seconds": dt, "vertices": int(vv.shape[0]),
+                          "triangles": int(ff.shape[0]), "hbm_gb_s_algorithmic": 2 * 16 * N ** 3 / dt / 1e9,
+                          "config": "BASELINE configs[4]: src/render_mc.py extract_mesh_CAP (count + scan + emit: the fields are "
+                                    "read twice, 16 B per grid point each time)"}))
+    del ndf_a, vec_a
     M = args.rays ** 2
     x = torch.from_numpy(synth.training_batch(M, seed=5)[0]).cuda()
     cfg = model.hip_cfg

@@ -61,6 +61,10 @@ SYMBOLS = {
     "dudf_loss_backward": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_int64, _DBL, ctypes.c_double, _P, _P, _P, ctypes.c_int, _P,
                                           ctypes.c_size_t, _P]),
+    "dudf_loss_backward_sweeps": (ctypes.c_int, [_CFG, ctypes.c_int, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                 _DBL, ctypes.c_double, _P, _P, _P, ctypes.c_size_t, _P]),
+    "dudf_weight_gradient": (ctypes.c_int, [_CFG, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P,
+                                            ctypes.c_int, _P, ctypes.c_size_t, _P]),
     "dudf_fields_forward": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_fields_backward": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int, _P,
                                             ctypes.c_size_t, _P]),

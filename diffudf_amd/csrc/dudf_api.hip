@@ -129,12 +129,21 @@ int forward_common(Ctx& c, const float* theta, const float* x, int train, bool r
     return 0;
 }
 
+// the adjoint sweeps; the weight gradients follow (all layers at once, or layer ranges through dudf_weight_gradient)
+int backward_sweeps(Ctx& c, const float* theta, int have_g);
+
 int backward_common(Ctx& c, const float* theta, int have_g, float* dtheta, int accumulate) {
     int rc;
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)c.lo.n_theta * sizeof(float), c.st);
         if (e != hipSuccess) return (int)e;
     }
+    if ((rc = backward_sweeps(c, theta, have_g))) return rc;
+    return dudf_launch_wgrad(c.lo, c.ws, dtheta, have_g, c.st);
+}
+
+int backward_sweeps(Ctx& c, const float* theta, int have_g) {
+    int rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     a.train = 1;
     if (have_g) {
@@ -142,8 +151,7 @@ int backward_common(Ctx& c, const float* theta, int have_g, float* dtheta, int a
     } else {
         a.have_e = 0;                                   // no df/dx terms: e_l == 0 in the reverse adjoint sweep
     }
-    if ((rc = run_sweep(SWEEP_ADJ_REV, c.lo, a, c.st))) return rc;
-    return dudf_launch_wgrad(c.lo, c.ws, dtheta, have_g, c.st);
+    return run_sweep(SWEEP_ADJ_REV, c.lo, a, c.st);
 }
 
 }  // namespace
@@ -380,6 +388,46 @@ int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta, co
     if ((rc = dudf_launch_loss_bwd(c.lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, c.ws, c.st)))
         return rc;
     return backward_common(c, theta, mode != DUDF_LOSS_S2, dtheta, accumulate);
+}
+
+int dudf_loss_backward_sweeps(const dudf_net_cfg* cfg, int mode, const float* theta, const float* normals, const float* sdf,
+                              int64_t n_local, int64_t n_global, int64_t n_hess, const double* weights, double alpha,
+                              const float* cot, const double* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    if (mode != DUDF_LOSS_S1 && mode != DUDF_LOSS_SIREN && mode != DUDF_LOSS_S2) return DUDF_E_BADMODE;
+    if (mode == DUDF_LOSS_S2 && !stats) return DUDF_E_BADMODE;
+    if (n_hess != 0 && !(mode == DUDF_LOSS_S1 && weights[2] != 0.0)) return DUDF_E_BADMODE;
+    Ctx c;
+    int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
+    if (rc) return rc;
+    if ((rc = dudf_launch_loss_bwd(c.lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, c.ws, c.st))) return rc;
+    return backward_sweeps(c, theta, mode != DUDF_LOSS_S2);
+}
+
+int dudf_weight_gradient(const dudf_net_cfg* cfg, int64_t n_local, int64_t n_hess, int have_gradient_terms, int layer_begin,
+                         int layer_end, float* dtheta, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    Ctx c;
+    int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
+    if (rc) return rc;
+    const DudfLayout& lo = c.lo;
+    if (layer_begin == -1) {                            // the two thin layers (0 and L) together: one pass of their kernel
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)lo.off_hid * sizeof(float), c.st);
+            if (e == hipSuccess) e = hipMemsetAsync(dtheta + lo.off_wo, 0, (size_t)(lo.n_theta - lo.off_wo) * sizeof(float), c.st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return dudf_launch_wgrad(lo, c.ws, dtheta, have_gradient_terms, c.st, 0, 1);
+    }
+    if (layer_begin < 0 || layer_end > lo.L + 1 || layer_begin >= layer_end) return DUDF_E_BADCFG;
+    if (!accumulate) {                                  // zero exactly the slices this call owns
+        auto zero = [&](int64_t off, int64_t cnt) { return hipMemsetAsync(dtheta + off, 0, (size_t)cnt * sizeof(float), c.st); };
+        hipError_t e = hipSuccess;
+        if (layer_begin <= 0) e = zero(0, lo.off_hid);
+        const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;
+        if (e == hipSuccess && he > hb) e = zero(lo.off_hid + (int64_t)(hb - 1) * lo.hid_stride, (int64_t)(he - hb) * lo.hid_stride);
+        if (e == hipSuccess && layer_end >= lo.L + 1) e = zero(lo.off_wo, lo.n_theta - lo.off_wo);
+        if (e != hipSuccess) return (int)e;
+    }
+    return dudf_launch_wgrad(lo, c.ws, dtheta, have_gradient_terms, c.st, layer_begin, layer_end);
 }
 
 int dudf_fields_forward(const dudf_net_cfg* cfg, const float* theta, const float* x, int64_t n, float* out_f,

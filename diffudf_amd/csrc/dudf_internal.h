@@ -131,7 +131,8 @@ int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st)
 int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
-int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st);
+int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st, int layer_begin = 0,
+                      int layer_end = 1 << 30);
 int dudf_launch_make_x4(const DudfLayout& lo, const float* x, float* ws, hipStream_t st);
 int dudf_launch_make_x4_grid(const DudfLayout& lo, int64_t grid_n, int64_t start, float* ws, hipStream_t st);
 int dudf_launch_field_features(const DudfLayout& lo, const float* ws, int inverse_mode, double alpha, float* out_df,

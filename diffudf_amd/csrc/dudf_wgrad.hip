@@ -39,6 +39,7 @@ struct WgradArgs {
     int steps_total;                    // np / KT
     int L;
     int have_g;                         // 0: loss without df/dx terms (loss_s2) -> only the zbar*s pair
+    int j0, nj;                         // hidden matrices [j0, j0 + nj) of this launch (matrix j = layer l = j + 2); grid.x = nj
     int Hs;                             // real layer width; the kernels' template H is the output TILE (<= 256):
                                         // blockIdx.z walks the (Hs/H)^2 tiles of a wider layer
 };
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo = wave / W::WI, wi = wave % W::WI;
     const int l32 = lane & 31, hh = lane >> 5;
-    const int j = blockIdx.x;                       // hidden matrix index: layer l = j + 2
+    const int j = blockIdx.x + a.j0;                // hidden matrix index: layer l = j + 2
     const int nsplit = gridDim.y;
     const int s0 = (int)((int64_t)a.steps_total * blockIdx.y / nsplit);
     const int s1 = (int)((int64_t)a.steps_total * (blockIdx.y + 1) / nsplit);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / W::WI, wi = wave % W::WI;
     const int l32 = lane & 31, hh = lane >> 5;
-    const int j = blockIdx.x;
+    const int j = blockIdx.x + a.j0;
     const int nsplit = gridDim.y;
     const int steps16 = a.steps_total * (KT / KB);
     const int s0 = (int)((int64_t)steps16 * blockIdx.y / nsplit);
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / W::WI, wi = wave % W::WI;
-    const int j = blockIdx.x;
+    const int j = blockIdx.x + a.j0;
     const int nsplit = gridDim.y;
     const int steps16 = a.steps_total * (KT / KB);
     const int s0 = (int)((int64_t)steps16 * blockIdx.y / nsplit);
@@ -732,7 +733,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     constexpr int NTHR = 64 * W::WO * W::WI;
     const size_t smem = 4 * (size_t)(H / 4) * KTP * 4 * sizeof(float);   // 2 buffers x (X tile + Y tile)
     const size_t smem_bf = (size_t)NRING * 2 * (H / 4) * KB * 4 * sizeof(float);   // ring of 4 x (X image + Y image)
-    const int nl = a.L - 1;
+    const int nl = a.nj;
     if (nl <= 0) return 0;
     const int tz = a.Hs / H, ntz = tz * tz;              // output tiles of a layer wider than the 256 x 256 tile
     int nsplit = 256 / (nl * ntz);                       // one resident workgroup per CU, a single round
@@ -802,14 +803,21 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st) {
+// dW / db of the layers [layer_begin, layer_end) in theta order: 0 = first layer (3 -> H), 1 .. L-1 = hidden matrices,
+// L = output layer.  The two thin layers share one kernel (one pass over the columns): it runs when either is asked for.
+int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g, hipStream_t st, int layer_begin,
+                      int layer_end) {
+    if (layer_begin < 0) layer_begin = 0;
+    if (layer_end > lo.L + 1) layer_end = lo.L + 1;
     WgradArgs a;
     a.Q = ws + lo.ws_Q; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z; a.S = ws + lo.ws_S; a.ncol_h = lo.ncol_h;
     a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.ncols / KT); a.L = lo.L;
     a.have_g = have_g; a.Hs = lo.H;
+    const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
+    a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;
-    {
+    if (a.nj > 0) {
         DudfProfScope prof(PROF_WGRAD_HIDDEN, st);
         switch (lo.H) {
             case 32: rc = launch_hidden<32>(a, st); break;
@@ -821,6 +829,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
         }
     }
     if (rc) return rc;
+    if (!(layer_begin <= 0 || layer_end >= lo.L + 1)) return 0;     // neither thin layer in range
     WgradSmallArgs s;
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;

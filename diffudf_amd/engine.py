@@ -50,36 +50,76 @@ class TrainEngine:
         if self.world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
-    def loss_and_grad(self, mode, x, normals, sdf, weights, alpha=100.0, n_global=None, n_hess=0):
+    def loss_and_grad(self, mode, x, normals, sdf, weights, alpha=100.0, n_global=None, n_hess=0, _adam_lr=None):
         """Fills self.terms (global loss terms) and self.dtheta (global gradient); returns self.terms.
-        n_hess: for loss_s1 with a Hessian weight, the number of leading on-surface points (C-ABI contract)."""
+        n_hess: for loss_s1 with a Hessian weight, the number of leading on-surface points (C-ABI contract).
+        (_adam_lr: `step()` passes its learning rate so that, with more than one rank, Adam runs per layer group as soon
+        as that group's all-reduce has completed.)"""
         ops = self.ops
         n = x.shape[0]
         n_global = n * self.world if n_global is None else n_global
         ws = ops.workspace_for(self.cfg, n, self.device, n_hess) if n_hess else ops.workspace_for(self.cfg, n, self.device)
         kw = {"n_hess": n_hess} if n_hess else {}
+        overlapped = self.world > 1 and hasattr(ops, "weight_gradient")
+        stats = None
         if mode == LOSS_S2:
             stats = ops.s2_forward_stats(self.cfg, self.theta, x, sdf, ws)
             self._allreduce(stats)                       # (count, sum, sum sq) of the on-surface predictions
             self.terms.zero_()
             self.terms[:2] = ops.s2_terms(stats, weights)
-            ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
-                              stats, ws, dtheta=self.dtheta)
-            self._allreduce(self.dtheta)
         else:
             terms = ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws, **kw)
-            ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
-                              None, ws, dtheta=self.dtheta, **kw)
             self.terms.copy_(terms)
-            self._allreduce(self.flat)                   # one collective: gradient + the four loss scalars
+        if not overlapped:
+            ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
+                              stats, ws, dtheta=self.dtheta, **kw)
+            # one collective: gradient + the four loss scalars (loss_s2's terms are global already)
+            self._allreduce(self.dtheta if mode == LOSS_S2 else self.flat)
+            if _adam_lr is not None:
+                self._adam_slice(0, self.theta.numel(), _adam_lr)
+            return self.terms
+        # ---- N > 1: the all-reduce of a layer group overlaps the weight-gradient GEMM of the next one (RCCL runs on its
+        # own stream behind the kernels already queued), and Adam for a group starts when its collective has completed
+        ops.loss_backward_sweeps(self.cfg, mode, self.theta, normals, sdf, n_global, weights, alpha, self.ones, stats, ws,
+                                 n_local=n, **kw)
+        have_g = mode != LOSS_S2
+        sl = ops.layer_slices(self.cfg)
+        L = self.cfg.n_hidden_layers
+        pending = []
+        for b, e in self._layer_groups(L):
+            ops.weight_gradient(self.cfg, n, have_g, b, e, self.dtheta, ws, **kw)
+            lo, hi = sl[b][0], sl[e - 1][1]
+            pending.append((torch.distributed.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True), lo, hi))
+        ops.weight_gradient(self.cfg, n, have_g, -1, 0, self.dtheta, ws, **kw)          # first and output layer together
+        tail_hi = self.flat.numel() if mode != LOSS_S2 else self.theta.numel()           # + the 4 loss terms unless global already
+        pending.append((torch.distributed.all_reduce(self.flat[sl[0][0]:sl[0][1]], group=self.pg, async_op=True), sl[0][0], sl[0][1]))
+        pending.append((torch.distributed.all_reduce(self.flat[sl[L][0]:tail_hi], group=self.pg, async_op=True), sl[L][0], sl[L][1]))
+        for work, lo, hi in pending:
+            work.wait()                                  # the compute stream waits for this collective only
+            if _adam_lr is not None:
+                self._adam_slice(lo, hi, _adam_lr)
         return self.terms
+
+    @staticmethod
+    def _layer_groups(L, target=3):
+        """Hidden matrices 1 .. L-1 in `target` contiguous groups, last layers first (their gradients are ready first
+        in the reference's backward; here all are ready, the order only staggers the collectives)."""
+        idx = list(range(1, L))
+        if not idx:
+            return []
+        k = min(target, len(idx))
+        cuts = [round(i * len(idx) / k) for i in range(k + 1)]
+        groups = [(idx[cuts[i]], idx[cuts[i + 1] - 1] + 1) for i in range(k) if cuts[i + 1] > cuts[i]]
+        return groups[::-1]
+
+    def _adam_slice(self, lo, hi, lr):
+        self.ops.adam_step(self.theta[lo:hi], self.dtheta[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.t, lr,
+                           self.betas[0], self.betas[1], self.eps)
 
     def adam(self, lr):
         self.t += 1
-        self.ops.adam_step(self.theta, self.dtheta, self.exp_avg, self.exp_avg_sq, self.t, lr, self.betas[0],
-                           self.betas[1], self.eps)
+        self._adam_slice(0, self.theta.numel(), lr)
 
     def step(self, mode, x, normals, sdf, weights, alpha=100.0, lr=1e-4, n_global=None, n_hess=0):
-        terms = self.loss_and_grad(mode, x, normals, sdf, weights, alpha, n_global, n_hess)
-        self.adam(lr)
-        return terms
+        self.t += 1
+        return self.loss_and_grad(mode, x, normals, sdf, weights, alpha, n_global, n_hess, _adam_lr=lr)

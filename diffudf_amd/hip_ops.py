@@ -296,6 +296,32 @@ def loss_backward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, c
     return dtheta
 
 
+def loss_backward_sweeps(cfg, mode, theta, normals, sdf, n_global, weights, alpha, cot, stats, ws, n_local, n_hess=0):
+    """loss cotangents + adjoint sweeps; the weight gradients follow through `weight_gradient` (layer ranges)."""
+    lib = _lib.load()
+    rc = lib.dudf_loss_backward_sweeps(ctypes.byref(cfg), mode, _ptr(theta), _ptr(normals), _ptr(sdf), int(n_local), int(n_global),
+                                       int(n_hess), _w4(weights), float(alpha), _ptr(cot), _ptr(stats), _ptr(ws.buf), ws.nbytes,
+                                       _stream())
+    _lib.check(rc, "dudf_loss_backward_sweeps")
+
+
+def layer_slices(cfg):
+    """[(begin, end)] offsets into theta of layer 0 .. L (state_dict order: weight then bias)."""
+    H, L = cfg.hidden, cfg.n_hidden_layers
+    out, off = [(0, 4 * H)], 4 * H
+    for _ in range(L - 1):
+        out.append((off, off + H * H + H)); off += H * H + H
+    out.append((off, off + H + 1))
+    return out
+
+
+def weight_gradient(cfg, n_local, have_g, layer_begin, layer_end, dtheta, ws, accumulate=False, n_hess=0):
+    lib = _lib.load()
+    rc = lib.dudf_weight_gradient(ctypes.byref(cfg), int(n_local), int(n_hess), 1 if have_g else 0, int(layer_begin),
+                                  int(layer_end), _ptr(dtheta), 1 if accumulate else 0, _ptr(ws.buf), ws.nbytes, _stream())
+    _lib.check(rc, "dudf_weight_gradient")
+
+
 def fields_forward(cfg, theta, x, ws):
     """(f (n,), df/dx (n,3)) with the training stash kept in ws (for fields_backward)."""
     lib = _lib.load()

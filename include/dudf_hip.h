@@ -170,6 +170,22 @@ int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta,
                        const float* cot, const double* stats, float* dtheta, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward in two steps, for overlapping the gradient all-reduce with the weight-gradient GEMM (one RCCL
+ * all-reduce per layer group while the next group is still being computed; reference: `train_loss.backward()` hands
+ * DistributedDataParallel its buckets in the same way):
+ *   dudf_loss_backward_sweeps: loss cotangents + the two adjoint sweeps (everything of dudf_loss_backward except dW, db);
+ *   dudf_weight_gradient: dW, db of the layers [layer_begin, layer_end) in theta order — 0 = first layer (3 -> H),
+ *       1 .. L-1 = the hidden matrices, L = output layer; the slices of dtheta those layers own are overwritten
+ *       (accumulate == 0) or added to.  The two thin layers (0 and L) are computed by ONE kernel (one pass over the
+ *       columns): layer_begin = -1 asks for exactly those two (layer_end ignored); a range that contains only one of them
+ *       must not be used with accumulate == 0 (the other one's slice would be added to without being zeroed).
+ *       have_gradient_terms = 0 for loss_s2, 1 otherwise. */
+int dudf_loss_backward_sweeps(const dudf_net_cfg* cfg, int mode, const float* theta, const float* normals, const float* sdf,
+                              int64_t n_local, int64_t n_global, int64_t n_hess, const double* weights, double alpha,
+                              const float* cot, const double* stats, void* workspace, size_t workspace_bytes, void* stream);
+int dudf_weight_gradient(const dudf_net_cfg* cfg, int64_t n_local, int64_t n_hess, int have_gradient_terms, int layer_begin,
+                         int layer_end, float* dtheta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Generic differentiable fields, for losses written by the caller on top of (f, df/dx) instead of the
  * reference's three: dudf_fields_forward = dudf_query with the training stash kept in `workspace`;
  * dudf_fields_backward = d(sum_p ybar[p]*f[p] + gbar[p].df/dx[p]) / d(theta), i.e. what autograd's

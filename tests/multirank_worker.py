@@ -42,10 +42,12 @@ def run_engine(case, out):
         x, nrm, sdf = [torch.from_numpy(np.concatenate([q[k] for q in b])).to(dev) for k in range(3)]
         sdf = sdf.reshape(-1)
         n_hess = int((sdf == 0).sum()) if case == "s1full" else 0
-        terms = eng.loss_and_grad(mode, x, nrm, sdf, w, 100.0, n_global=N_GLOBAL, n_hess=n_hess)
-        if t == 0:
+        if t == 0:                       # gradient first, then Adam on the whole buffer
+            terms = eng.loss_and_grad(mode, x, nrm, sdf, w, 100.0, n_global=N_GLOBAL, n_hess=n_hess)
             first_grad = eng.dtheta.cpu().numpy().copy()
-        eng.adam(lr)
+            eng.adam(lr)
+        else:                            # what bench.py and train loops call: with N > 1 ranks, per-layer-group all-reduce
+            terms = eng.step(mode, x, nrm, sdf, w, 100.0, lr=lr, n_global=N_GLOBAL, n_hess=n_hess)   # overlapped with the GEMM, Adam per group
         hist.append(terms.cpu().numpy().copy())
     torch.cuda.synchronize()
     if rank == 0:

@@ -340,3 +340,34 @@ np.savez(sys.argv[1], **out)
     assert rel(d["shard_g0"], d["eik_g0"]) < 2e-6                 # shards: equal to rounding, not to the bit
     moved = sum(not np.array_equal(a[k + "0"], a[k + "1"]) for k in ("eik_g", "full_g", "s2_g", "shard_g"))
     print("deterministic mode: all bit-identical; default mode: %d of 4 gradients differ in the last bits between launches" % moved)
+
+
+@pytest.mark.parametrize("mode,w", [(0, W_S1EIK), (1, W_S2)])
+def test_weight_gradient_by_layer_ranges(hip, mode, w):
+    """dudf_loss_backward_sweeps + dudf_weight_gradient over layer groups (what the multi-GPU step overlaps with its
+    all-reduces) reproduces dudf_loss_backward: every slice of d(theta) is written by exactly one call."""
+    hidden, n, seed = [256] * 8, 1000, 123
+    P, theta, x, nrm, sdf = setup(hidden, n, seed)
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda")
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    ones = torch.ones(4, device="cuda")
+
+    def forward():
+        if mode == 1:
+            return hip.s2_forward_stats(cfg, th, xd, sd, ws)
+        hip.loss_forward(cfg, mode, th, xd, nd, sd, n, w, 100.0, ws)
+        return None
+    stats = forward()
+    ref = hip.loss_backward(cfg, mode, th, xd, nd, sd, n, w, 100.0, ones, stats, ws).clone()
+    stats = forward()
+    got = torch.full_like(ref, float("nan"))                     # every element must be overwritten
+    hip.loss_backward_sweeps(cfg, mode, th, nd, sd, n, w, 100.0, ones, stats, ws, n_local=n)
+    L = len(hidden)
+    for b, e in ((6, 8), (3, 6), (1, 3)):
+        hip.weight_gradient(cfg, n, mode != 1, b, e, got, ws)
+    hip.weight_gradient(cfg, n, mode != 1, -1, 0, got, ws)
+    assert torch.isfinite(got).all()
+    assert rel(got.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    sl = hip.layer_slices(cfg)
+    assert sl[0] == (0, 4 * 256) and sl[L][1] == ref.numel() and all(sl[i][1] == sl[i + 1][0] for i in range(L))
