@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Mesh extraction from a trained network — reference generate_mc.py:9-67 `generate_mc`, with what this build's hot
+path covers: `extract_fields` (value + gradient on the N^3 grid) feeding the CAP-UDF extractor, both on the device.
+
+    python generate_mc.py <config.json>            keys as the reference's configs/mc_cfg.json
+
+algorithm 'cap' is built.  'meshudf' (the Lewiner-table marching cubes of
+src/marching_cubes) and 'siren' (skimage's marching cubes on an SDF) are outside it: they raise.  'both' — what
+train.py asks for with gt_mode 'tanh' — writes the CAP mesh (`*_CAP.obj`) and returns (None, meshCAP)."""
+import json
+import sys
+
+import torch
+
+from src.model import SIREN
+from src.render_mc import extract_fields, extract_mesh_CAP
+
+
+def generate_mc(model, gt_mode, device, N, output_path, alpha=None, algorithm='cap', from_file=None):
+    if from_file is not None:
+        model = SIREN(n_in_features=3, n_out_features=1, hidden_layer_config=from_file["hidden_layer_nodes"],
+                      w0=from_file["w0"], ww=None, activation=from_file.get('activation', 'sine'))
+        model.load_state_dict(torch.load(from_file["model_path"], weights_only=True))
+    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    model.to(dev)
+    if algorithm in ('cap', 'both'):
+        u, g = extract_fields(model, torch.Tensor([[]]).to(dev), N, gt_mode, dev, alpha)
+        mesh = extract_mesh_CAP(u, g, N)                       # device tensors straight through: no host round trip
+        if algorithm == 'cap':
+            mesh.export(output_path)
+            print(f'Saved to {output_path}')
+            return mesh
+        dot = output_path.rfind('.')
+        path_cap = output_path[:dot] + '_CAP' + output_path[dot:]
+        mesh.export(path_cap)
+        print(f'Saved to {path_cap} (the MeshUDF half of algorithm "both" is not part of this build)')
+        return None, mesh
+    raise ValueError(f"algorithm '{algorithm}' is not part of this build (CAP-UDF extraction only: 'cap' / 'both')")
+
+
+if __name__ == "__main__":
+    cfg = json.load(open(sys.argv[1]))
+    generate_mc(None, cfg["gt_mode"], cfg.get("device", 0), cfg["nsamples"], cfg["output_path"], cfg.get("alpha"),
+                cfg.get("algorithm", "cap"), from_file={"w0": cfg["w0"], "model_path": cfg["model_path"],
+                                                        "hidden_layer_nodes": cfg["hidden_layer_nodes"]})

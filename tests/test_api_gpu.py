@@ -213,6 +213,22 @@ def test_train_cli_loop_runs(tmp_path):
     assert (base / "params.json").exists()
 
 
+def test_train_cli_post_training_artefacts(tmp_path):
+    """reference train.py:403-446: with `resolution != 0` the run ends with the field slice of the best model
+    (generate_df) and its mesh (generate_mc; the CAP-UDF half of algorithm 'both'), here on the device."""
+    import train
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "train_synth_eikonal.json")))
+    cfg.update({"num_epochs": 3, "s1_epochs": 2, "warmup_epochs": 1, "batch_size": 3000, "resolution": 24,
+                "checkpoint_path": str(tmp_path), "experiment_name": "t",
+                "network": {"hidden_layer_nodes": [64] * 4, "w0": 30, "pretrained_dict": "None"}})
+    t, meshes = train.setup_train(cfg, 0)
+    rec = tmp_path / "t" / "reconstructions"
+    assert (rec / "field_slice.npz").exists() and (rec / "pred_grad.png").exists() and (rec / "mc_mesh_best_CAP.obj").exists()
+    sl = np.load(rec / "field_slice.npz")
+    assert sl["pred_distances"].shape == (512 * 512, 1) and np.isfinite(sl["pred_grad_norm"]).all()
+    assert meshes[0] is None and np.asarray(meshes[1].faces).shape[1:] == (3,)
+
+
 def test_extract_fields_and_frames(golden_dir):
     """reference src/render_mc.py:20-99 field part and src/render_st.py:57-62, against the fixture made by the
     reference's evaluate() + its inverse(), with the reference's own epilogue restated in numpy."""

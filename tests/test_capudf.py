@@ -137,3 +137,29 @@ def test_extract_mesh_cap_mirror_and_pipeline(tmp_path):
     vo2, to2, _ = C.extract_mesh_CAP(df.cpu().numpy(), vecs.cpu().numpy(), n)
     assert np.array_equal(np.asarray(m2.faces), to2)
     assert len(vo2) == len(m2.vertices) and (len(vo2) == 0 or np.abs(np.asarray(m2.vertices) - vo2).max() < 1e-12)
+
+
+@pytest.mark.gpu
+def test_extractor_edge_cases():
+    """nothing active (empty outputs, no emit launch), the smallest grid (2^3 = one cell), NaNs in the field (skipped
+    like `np.min(...) > threshold` skips them in the reference: a NaN minimum compares False ... and then `res.min() < 0`
+    is False too), bad shapes."""
+    import torch
+    from diffudf_amd import hip_ops, _lib
+    n = 16
+    far = torch.full((n, n, n), 0.5, device="cuda"); vec = torch.zeros(n, n, n, 3, device="cuda"); vec[..., 2] = 1.0
+    v, t, c = hip_ops.capudf_extract(far, vec, want_cells=True)
+    assert v.shape == (0, 3) and t.shape == (0, 3) and c.shape == (0, 3)
+    one = torch.tensor([0.25, 0.25, 0.25, 0.25, 0.75, 0.75, 0.75, 0.75], device="cuda").reshape(2, 2, 2).contiguous() * 0.01
+    g = torch.zeros(2, 2, 2, 3, device="cuda"); g[0, :, :, 0] = 1.0; g[1, :, :, 0] = -1.0     # the sheet lies between i = 0 and i = 1
+    v, t, c = hip_ops.capudf_extract(one, g, want_cells=True)
+    vo, to, co = C.extract_mesh_CAP(one.cpu().numpy(), g.cpu().numpy(), 2)
+    assert np.array_equal(c.cpu().numpy(), co) and np.array_equal(t.cpu().numpy(), to) and len(v) == 4
+    assert np.abs(v.cpu().numpy() - vo).max() < 1e-12 and np.allclose(v.cpu().numpy()[:, 0], -1 + 2 * 0.25)
+    ndf, vecf = analytic_fields(n, "sphere")
+    ndf[3:6, 3:6, 3:6] = np.nan
+    vo, to, co = C.extract_mesh_CAP(ndf, vecf, n, threshold=0.2)
+    v, t, c = hip_ops.capudf_extract(torch.from_numpy(ndf).cuda(), torch.from_numpy(vecf).cuda(), threshold=0.2, want_cells=True)
+    assert np.array_equal(c.cpu().numpy(), co) and np.array_equal(t.cpu().numpy(), to)
+    with pytest.raises(_lib.DudfError):
+        hip_ops.capudf_extract(far, vec[:, :, :, :2].contiguous())
