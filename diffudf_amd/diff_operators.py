@@ -4,8 +4,11 @@ instead of repeated `torch.autograd.grad`.
 
 `gradient(y, x)` keeps the reference call shape: `y`/`x` are the "model_out"/"model_in" entries of
 `SIREN.forward(...)`.  The result is the analytic reverse sweep  a_{l-1} = W_l^T (w0 cos(w0 z_l) * a_l)
-evaluated by the kernel (SWEEP_REV); it is a plain tensor — training through df/dx goes through the fused
-losses in `loss_functions.py` (or `fields()` below for hand-written losses), which carry their own backward.
+evaluated by the kernel (SWEEP_REV); with autograd enabled it is a node of the graph (its backward = the adjoint
+sweeps + weight-gradient GEMM), so a loss written on it in plain PyTorch trains the network as with the reference's
+`create_graph=True`.  The fused losses in `loss_functions.py` (one forward, one backward for all terms) remain the fast
+path; `fields()` below returns value and gradient from one forward.  `hessian` / `laplace` / `divergence` are queries
+(no graph): the Hessian enters training only through `loss_s1`'s fused term.
 """
 import torch
 
@@ -80,14 +83,45 @@ def _kind(y, coords):
                     "arbitrary functions of the output: use fields())")
 
 
+class _InputGradient(torch.autograd.Function):
+    """df/dx as a node of the autograd graph: the reference builds it with `create_graph=True` so that a loss written on
+    it trains the network (src/diff_operators.py:208-212, used by src/loss_functions.py:31-32, :89-101).  Forward: the fused
+    value + reverse sweeps with the training stash kept; backward: the two adjoint sweeps + weight-gradient GEMM with the
+    incoming cotangent of df/dx (`dudf_fields_backward`).  The stash lives in the network's workspace, so — like the
+    reference's graph — call backward() before the next forward of a different batch on the same network."""
+
+    @staticmethod
+    def forward(ctx, model, coords, *params):
+        x2 = coords.detach().reshape(-1, 3).contiguous().float()
+        ws = hip_ops.workspace_for(model.hip_cfg, x2.shape[0], x2.device)
+        _, g = hip_ops.fields_forward(model.hip_cfg, model.flat_parameters(), x2, ws)
+        ctx.model, ctx.x2, ctx.shape = model, x2, coords.shape
+        return g.reshape(coords.shape)
+
+    @staticmethod
+    def backward(ctx, gbar):
+        model, x2 = ctx.model, ctx.x2
+        theta = model.flat_parameters()
+        ws = hip_ops.workspace_for(model.hip_cfg, x2.shape[0], x2.device)
+        hip_ops.fields_forward(model.hip_cfg, theta, x2, ws)            # the stash may belong to another node by now
+        zeros = torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
+        dtheta = hip_ops.fields_backward(model.hip_cfg, theta, x2, zeros, gbar.reshape(-1, 3).contiguous().float(), ws)
+        return (None, None) + tuple(model.split_flat(dtheta))
+
+
 def gradient(y, x, grad_outputs=None):
-    """dy/dx, shaped like x — reference src/diff_operators.py:208-212."""
+    """dy/dx, shaped like x — reference src/diff_operators.py:208-212.  With autograd enabled the result is part of the
+    graph (differentiable with respect to the network's parameters, like the reference's `create_graph=True`); inside
+    `torch.no_grad()` it is a plain query."""
     model, coords = _source(y, x)
     if _kind(y, coords) != "value":
         raise DudfError("gradient(y, x): `y` must be the model output; for second derivatives use hessian / laplace")
-    x2 = coords.detach().reshape(-1, 3)
-    _, g = hip_ops.query(model.hip_cfg, model.flat_parameters(), x2, want_grad=True)
-    g = g.reshape(coords.shape)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        g = _InputGradient.apply(model, coords, *model.parameters())
+    else:
+        x2 = coords.detach().reshape(-1, 3)
+        _, g = hip_ops.query(model.hip_cfg, model.flat_parameters(), x2, want_grad=True)
+        g = g.reshape(coords.shape)
     if grad_outputs is not None:
         g = g * grad_outputs.reshape(coords.shape[:-1] + (1,))
         return tag_field(g, "from:grad")

@@ -154,7 +154,8 @@ def test_forward_gradient_evaluate_contract(golden_dir):
     g = gradient(y, xin)
     assert g.shape == xin.shape
     assert rel(y.detach().cpu().numpy()[0], G["values"]) < 2e-5
-    assert rel(g.cpu().numpy()[0], G["gradients"]) < 5e-5
+    assert g.requires_grad                                   # part of the graph, like the reference's create_graph=True
+    assert rel(g.detach().cpu().numpy()[0], G["gradients"]) < 5e-5
     hs = hessian(y, xin)
     assert hs.shape == (1, n ** 3, 3, 3) and rel(hs.cpu().numpy()[0], G["hessians"]) < 1e-4
     # (M,3) inputs as reference src/render_mc.py:340 uses them

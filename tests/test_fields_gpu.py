@@ -214,3 +214,36 @@ def test_curvature_and_frame_at_width_512():
     assert ok.sum() > 40
     assert rel((J.cpu().numpy() * sgn[:, None, None])[ok], Jo[ok]) < 2e-4
     assert rel((mean.cpu().numpy() * sgn)[ok], mo[ok]) < 2e-4
+
+
+def test_gradient_is_part_of_the_graph():
+    """reference src/diff_operators.py:208-212 builds df/dx with create_graph=True: a loss written in plain PyTorch on
+    `model(x)['model_out']` and `gradient(y, x)` — here the reference's own loss_siren terms, src/loss_functions.py:82-104,
+    restated on the two tensors — must train the network: parameter gradients against the fused loss_siren's."""
+    from src import diff_operators as dif
+    from src.loss_functions import loss_siren
+    model, P = make_model([256] * 8, 123)
+    x, nrm, sdf = [torch.from_numpy(a).cuda() for a in synth.training_batch(900, seed=4, step=0)]
+    w = [3e3, 1e2, 1e2, 5e1]
+    mo = model(x[None])
+    y, xin = mo["model_out"], mo["model_in"]
+    g = dif.gradient(y, xin)
+    assert g.requires_grad and g.shape == (1, 900, 3)
+    on = (sdf[None] == 0)
+    t0 = torch.where(on, y.abs(), torch.zeros_like(y)).mean() * w[0]
+    t1 = torch.where(~on, torch.exp(-1e2 * y.abs()), torch.zeros_like(y)).mean() * w[1]
+    cosv = torch.nn.functional.cosine_similarity(g, nrm[None], dim=-1)[..., None]
+    t2 = torch.where(on, 1 - cosv, torch.zeros_like(y)).mean() * w[2]
+    t3 = ((g.norm(dim=-1) - 1) ** 2).mean() * w[3]
+    (t0 + t1 + t2 + t3).backward()
+    got = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in model.parameters()])
+    model.zero_grad()
+    terms = loss_siren(model, x[None], {"normals": nrm[None], "sdf": sdf[None]}, w)
+    sum(terms.values()).backward()
+    ref = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in model.parameters()])
+    tv = np.array([t.item() for t in terms.values()])
+    assert rel(np.array([t0.item(), t1.item(), t2.item(), t3.item()]), tv) < 1e-5
+    assert rel(got, ref) < 2e-5
+    with torch.no_grad():                                # a plain query outside the graph
+        mo2 = model(x[None])
+        assert not dif.gradient(mo2["model_out"], mo2["model_in"]).requires_grad
