@@ -551,19 +551,24 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     f32x4 accg = {0, 0, 0, 0};
     // ---- the elementwise tails of all 32 tiles of `layer` (operands one pair ahead), stash stores, output stage ----
     auto tail_burst = [&](int layer, bool last) {
-        f32x4 o1[2], o2[2], o3[2], bs[2];
+        // operand ring: the stash operands of tile T + PD are requested when tile T has been consumed.  One tile of tail is
+        // ~100 instructions, an HBM round trip ~2 us: with the operands only one tile ahead the burst waited for memory at
+        // every tile (it took about as long as the layer's whole k-loop); the forward sweep only reads its bias (cached).
+        constexpr int PD = (SW == SWEEP_FWD) ? 2 : 8;
+        f32x4 o1[PD], o2[PD], o3[PD], bs[PD];
         auto ld = [&](int T, int s) {
             epilogue_loads<SW, FL>(a, stash_base(layer, T), vo, o1[s], o2[s], o3[s]);
             if constexpr (SW == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
         };
-        ld(0, 0);
+#pragma unroll
+        for (int T = 0; T < PD; ++T) ld(T, T);
 #pragma unroll
         for (int T = 0; T < G::NT; ++T) {
-            const int s = T & 1;
-            if (T + 1 < G::NT) ld(T + 1, s ^ 1);
+            const int s = T % PD;
             f32x4 z = acc[T];
             if constexpr (SW == SWEEP_FWD) z += bs[s];
             const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, true);
+            if (T + PD < G::NT) ld(T + PD, s);
             if (last) {
                 if constexpr (SW == SWEEP_FWD) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q);
