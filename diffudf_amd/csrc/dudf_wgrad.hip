@@ -834,11 +834,14 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
-    static const int ppb = [] { const char* e = getenv("DUDF_SMALL_PPB"); return e ? atoi(e) : 2048; }();   // A/B testing (1024: 0.156 ms, 2048: 0.14, 4096: 0.21)
+    static const int ppb = [] { const char* e = getenv("DUDF_SMALL_PPB"); return e ? atoi(e) : 4096; }();   // A/B testing: with 16 feature-quad groups 4096 columns per block is best (0.096 ms;
+                                                                       // round 1: 1024 columns x 4 groups, 0.156 ms)
     s.pts_per_block = dudf_deterministic() ? (int)lo.ncols : ppb;
     const int grid = (int)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block);
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
-    const int gy = (lo.H / 4 >= 16) ? 4 : 1;
+    static const int gy_env = [] { const char* e = getenv("DUDF_SMALL_GY"); return e ? atoi(e) : 0; }();   // A/B testing
+    const int fqn = lo.H / 4;                                              // feature quads; a block's 4 waves take one each per round:
+    const int gy = gy_env > 0 ? gy_env : (fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1));   // up to 16 groups -> more loads in flight per CU
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid, gy), dim3(256), 0, st, s);
     return (int)hipGetLastError();
 }
