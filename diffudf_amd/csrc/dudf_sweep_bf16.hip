@@ -126,12 +126,24 @@ __device__ __forceinline__ void dma_wait_b() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
+#if DUDF_SWEEP_DBG & 128
+// phase stamps (timing experiments): [sweep][wave][k-block][stamp] of one workgroup's first pass, layer 3
+__device__ unsigned long long g_stamp[4][8][8][8];
+extern "C" int dudf_dbg_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp));
+}
+#define DUDF_STAMP(i) do { if (stamp_on && j == 3) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0) g_stamp[BS & 3][wave][kb][i] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define DUDF_STAMP(i) do { } while (0)
+#endif
 struct TailOps { f32x4 o1a, o2a, o3a, o1b, o2b, o3b, ba, bb; };   // operands of one pair of tiles (+ bias, forward sweeps)
 
 // One pass: the workgroup's waves 0..nact-1 take the 16-column groups g_first.. through a whole sweep.  Waves beyond
 // nact (the last, partial pass of a workgroup's share) only keep the weight stream and the barriers going.
 template <int H, int SW, int FL>
-__device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
+__device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc,
+                                             const bool stamp_on = false) {
     using G = GeoB<H>;
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
@@ -249,6 +261,24 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     dma_wait_b<0>();                                   // once per tile: chunks 0 and 1 and everything above
     __syncthreads();
     constexpr int kYoung = younger_ops<SW, FL>();
+    // The two waves of a SIMD (w, w + 4) leave every k-block barrier together.  With the same program order both run
+    // their tail (vector ALU) at the same time and then collide on the matrix pipe: the step costs tail + MFMAs of both.
+    // Waves 4-7 therefore run their MFMAs FIRST and the tail of the next step behind them (the tail only needs the
+    // previous layer's accumulators, not this step's): each half's tail falls beside the other half's MFMAs.
+    #ifdef DUDF_LATE_FORCE                                 // tests/isa_contract.py: one half's program order at a time, branch-free
+    const bool late = !HS && DUDF_LATE_FORCE;
+#else
+    const bool late = !HS && __builtin_amdgcn_readfirstlane((int)((a.prio & 4) == 0 && wave >= NWB / 2)) != 0;   // DUDF_SWEEP_PRIO=4: off (A/B)
+#endif
+    // feed slot: after which tile's MFMAs a wave issues its DMA pieces and operand loads (-1: at the top of the step);
+    // tail slot: after which tile's MFMAs it runs the tail of the next step.  A = waves 0-3, B = waves 4-7 (when `late`).
+#ifndef DUDF_FA
+#define DUDF_FA -1
+#define DUDF_TA 0
+#define DUDF_FB (BS == SWEEP_FWD ? 15 : 7)
+#define DUDF_TB 15
+#endif
+    constexpr int FA = DUDF_FA, TA = DUDF_TA * (G::NT - 1) / 15, FB = DUDF_FB < 0 ? -1 : DUDF_FB * (G::NT - 1) / 15, TB = DUDF_TB * (G::NT - 1) / 15;
     for (int j = 0; j < nhid; ++j) {
         const int lin = in_layer(j), lnx = in_layer(j + 1);
 #pragma unroll
@@ -261,20 +291,28 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 #endif
                 return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
             };
+            DUDF_STAMP(0);
             if constexpr (!HS) ops_cur = ops_n1;
             pin_ops(ops_cur);
             const bool more = c + 2 < total;
-            if (more) dma_issue<H>(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB, voff, wave);
             auto load_after_next = [&](TailOps& o) {                 // operands of tail c+2
                 if (kb + 2 < G::NKB) load_ops(lin, kb + 2, o);
                 else load_ops(lnx, kb + 2 - G::NKB, o);
             };
-            if constexpr (!HS) load_after_next(ops_n1);              // one full step ahead
+            auto feed = [&]() {                                      // this step's DMA pieces, then the operand loads
+                if (more) dma_issue<H>(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB, voff, wave);
+                if constexpr (!HS) load_after_next(ops_n1);          // one full step ahead
+            };
+            if ((FA < 0 && !late) || (FB < 0 && late)) feed();
+            DUDF_STAMP(1);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 nh, nm, nl;
             // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
             // chunk DMA on the LDS, one tile of distance does not cover the read latency
             bf16x8 an[2][3] = {{frag(0, 0), frag(0, 1), frag(0, 2)}, {frag(1, 0), frag(1, 1), frag(1, 2)}};
+#ifdef DUDF_MPRIO
+            __builtin_amdgcn_s_setprio(1);                              // the wave that multiplies wins the issue arbitration
+#endif
 #pragma unroll
             for (int T = 0; T < G::NT; ++T) {
                 const bf16x8 ah = an[T & 1][0], am = an[T & 1][1], al = an[T & 1][2];
@@ -292,13 +330,32 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 cc = mfma_b(ah, as_bf(bm), cc);
                 cc = mfma_b(ah, as_bf(bh), cc);
                 acc[T] = cc;
-                if (T == 0 && kb + 1 < G::NKB) {                        // the next step's B operand, between the MFMAs
-                    f32x4 e0, e1;                                       // (spreading it over several tiles: no gain —
-                    run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);   // the SIMD's other wave
-                    split8(e0, e1, nh, nm, nl);                         //  covers the block)
+                if ((T == FA && !late) || (T == FB && late)) {                       // the late half issues its DMA pieces (60-180 cycles
+                    __builtin_amdgcn_sched_barrier(0);                  // of issue each) under the other half's MFMAs
+                    DUDF_STAMP(6);
+                    feed();
+                    DUDF_STAMP(7);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kb + 1 < G::NKB && ((T == TA && !late) || (T == TB && late))) {   // the next step's B operand
+                    if (T != 0) __builtin_amdgcn_sched_barrier(0);
+                    DUDF_STAMP(2);
+#ifdef DUDF_MPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                    f32x4 e0, e1;
+                    run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
+                    split8(e0, e1, nh, nm, nl);
                     if constexpr (HS) load_after_next(ops_cur);
+#ifdef DUDF_MPRIO
+                    if (T + 1 < G::NT) __builtin_amdgcn_s_setprio(1);
+#endif
+                    DUDF_STAMP(3);
                 }
             }
+#ifdef DUDF_MPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
                 run_tail(lnx, 0, acc[0], acc[1], ops_cur, fin0, fin1);
                 split8(fin0, fin1, nh, nm, nl);
@@ -308,10 +365,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             }
             bh = nh; bm = nm; bl = nl;
             gc = (gc + 1) % 3;
+            DUDF_STAMP(4);
 #if !(DUDF_SWEEP_DBG & 8)
             if (more) dma_wait_b<2 * kYoung + G::NDMA>();               // chunk c+1 landed; c+2 and two steps' stash traffic stay in flight
             else dma_wait_b<0>();
 #endif
+            DUDF_STAMP(5);
 #if !(DUDF_SWEEP_DBG & 16)
             __syncthreads();
 #endif
@@ -360,7 +419,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 }
 
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) {
+__device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
     // the two waves of a SIMD (w, w + 4) leave every k-block barrier in lockstep: tails coincide, MFMA streams collide.
@@ -373,8 +432,23 @@ __global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) {
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
-        sweep_tile_b<H, SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc);
+        sweep_tile_b<H, SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && blockIdx.x == 100 && g == g0);
 }
+// Two code generations of the same body.  The packed fp32 instructions (v_pk_fma_f32 ...) halve the vector-ALU issue
+// slots of a tail, but they do not execute beside the SIMD partner's MFMAs (tools/micro/coissue.hip: 48 v_pk_fma_f32 +
+// 24 MFMAs take the SUM of their times, 48 v_fma_f32 + 24 MFMAs the maximum + 25 %).  The forward sweep, whose sin/cos
+// tail is as long as its MFMA stream, is therefore built WITHOUT them and overlaps the two; the other sweeps (short
+// tails, bound by the stash stream) keep them.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DUDF_NO_PK __attribute__((target("no-packed-fp32-ops")))
+#else
+#define DUDF_NO_PK
+#endif
+template <int SW> constexpr bool sweep_no_pk() { return SW == SWEEP_FWD; }
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_bf16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
 
 // theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L
 template <int H>
@@ -409,6 +483,11 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
     }
 }
 
+template <int H, int SW, int FL>
+const void* sweep_kernel_ptr() {
+    if constexpr (sweep_no_pk<SW>()) return reinterpret_cast<const void*>(&sweep_bf16_np_kernel<H, SW, FL>);
+    else return reinterpret_cast<const void*>(&sweep_bf16_kernel<H, SW, FL>);
+}
 template <int H>
 int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoB<H>;
@@ -421,12 +500,15 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     do {                                                                                                    \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_bf16_kernel<H, SW, FL>),           \
+            e = hipFuncSetAttribute(sweep_kernel_ptr<H, SW, FL>(),                                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
             if (e != hipSuccess) return (int)e;                                                             \
             attr_done = true;                                                                               \
         }                                                                                                   \
-        hipLaunchKernelGGL((sweep_bf16_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);         \
+        if constexpr (sweep_no_pk<SW>())                                                                    \
+            hipLaunchKernelGGL((sweep_bf16_np_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);  \
+        else                                                                                                \
+            hipLaunchKernelGGL((sweep_bf16_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);     \
     } while (0)
     switch (which) {
         case SWEEP_FWD:

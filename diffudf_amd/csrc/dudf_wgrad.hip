@@ -529,6 +529,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
         if (nit > 3) load_raw_plain(3, R0);
     }
     __syncthreads();
+    // VAR bit 3: the two waves of a SIMD (w, w + 4) run slice and MFMA group in OPPOSITE order, so that one's slice (vector
+    // ALU) falls beside the other's MFMAs instead of both splitting and then both multiplying
+    const bool late = (VAR & 8) != 0 && __builtin_amdgcn_readfirstlane((int)(wave >= NW_ / 2)) != 0;
     // one stage: the next stage's registers -> pieces (its set is then refilled with the stage three further on, so three
     // stages = 96 KiB per CU stay in flight: with one, the kernel measured latency-bound at 2 TB/s), then 48 MFMAs
     auto stage = [&](int it, RawSet& r, auto hot) {
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
                 for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n, pc);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (HOT && !(DBG & 1)) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
-                if constexpr (!(DBG & 8)) { if (more) split_slice(it + 1, r, n); }
+                if constexpr (!(DBG & 8)) { if (more && !late) split_slice(it + 1, r, n); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
@@ -590,6 +593,10 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
                 acc[m][n] = c;
             }
             if constexpr (IL) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IL && (VAR & 8) != 0 && !(DBG & 8)) {       // waves 4-7: this group's slice BEHIND its MFMAs
+                if (more && late) split_slice(it + 1, r, n);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if constexpr (IL) {
             if constexpr (HOT) { if constexpr (!(DBG & 1)) load_raw(it + 4, r); }
@@ -770,15 +777,16 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                 }
                 // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7} (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split,
                 // bit 2 static priority for waves 0-3 (stagger)
-                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 7 : 3; }();
+                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 3; }();
                 if (!attr3) {
                     hipError_t e = hipSuccess;
-                    const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
+                    const void* fns[6] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 5>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>)};
-                    for (int v = 0; v < 5 && e == hipSuccess; ++v)
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 11>)};
+                    for (int v = 0; v < 6 && e == hipSuccess; ++v)
                         e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
@@ -790,6 +798,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     case 3: DUDF_WG_GO(3); break;
                     case 5: DUDF_WG_GO(5); break;
                     case 7: DUDF_WG_GO(7); break;
+                    case 11: DUDF_WG_GO(11); break;
                     default: DUDF_WG_GO(3); break;
                 }
 #undef DUDF_WG_GO

@@ -11,9 +11,9 @@ import subprocess
 import sys
 
 
-def emit_asm(src, out):
+def emit_asm(src, out, flags=()):
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S",
-                    "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+                    "--cuda-device-only", *flags, src, "-o", out], check=True, stderr=subprocess.DEVNULL)
 
 
 def analyse(asm_path):
@@ -60,7 +60,7 @@ def analyse_bf16(asm_path, ndma=6):
     {"steps": [(dma pieces, compiler ops, N)], "idle": [N of the idle-wave loop], "scratch": count}."""
     txt = open(asm_path).read()
     out = {}
-    for m in re.finditer(r"^(_ZN\w*sweep_bf16_kernelILi256ELi(\d)ELi(\d)E\w*):[^\n]*$", txt, re.M):
+    for m in re.finditer(r"^(_ZN\w*sweep_bf16_(?:np_)?kernelILi256ELi(\d)ELi(\d)E\w*):[^\n]*$", txt, re.M):
         end = txt.index("s_endpgm", m.end())
         body = txt[m.end():end]
         in_asm, dma, other, scratch, steps, idle = False, 0, 0, 0, [], []

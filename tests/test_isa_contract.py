@@ -33,22 +33,41 @@ def test_bf16_sweep_wait_counts(tmp_path):
     """dudf_sweep_bf16.hip: every step's counted wait leaves exactly this step's DMA pieces and two steps of stash
     traffic in flight (a larger N would let a wave read a weight chunk that has not landed; a smaller one only
     stalls), the idle-wave loop waits for all but its newest pieces, and nothing spills at 2 waves per SIMD."""
+    src = os.path.join(REPO, "diffudf_amd", "csrc", "dudf_sweep_bf16.hip")
+    keys = {(0, 3), (0, 2), (0, 0), (1, 1), (1, 0), (2, 0), (3, 1), (3, 0),
+            (4, 1), (4, 0), (5, 1), (5, 0), (6, 0), (7, 0), (8, 0)}                        # + the Hessian-quad variants
+    # The shipped kernels hold BOTH halves' program orders behind a wave-uniform branch (waves 0-3: DMA pieces and
+    # operand loads at the top of a step, tail early; waves 4-7: MFMAs first, then DMA pieces, loads and tail).  The
+    # count is a property of each order: check each one in a build where that order is the only one (straight-line steps).
+    for force in (0, 1):
+        asm = str(tmp_path / f"sweep_bf16_{force}.s")
+        emit_asm(src, asm, flags=(f"-DDUDF_LATE_FORCE={force}",))
+        res = analyse_bf16(asm)
+        assert set(res) == keys
+        for key, v in res.items():
+            assert v["scratch"] == 0, (force, key)
+            for dma, ops, n in v["steps"]:
+                assert n <= 2 * ops + dma, f"late={force} sweep_bf16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) with {ops} ops/step"
+            # the unrolled steps of a layer (the first entry also carries the first layer's prologue traffic)
+            kmin = min(s[1] for s in v["steps"] if s[0] == 6)
+            steady = [s for s in v["steps"] if s[0] == 6 and s[1] == kmin]
+            assert len(steady) >= 7, (force, key, v["steps"])
+            for dma, ops, n in steady:
+                assert n == 2 * ops + dma, (force, key, dma, ops, n)   # and not needlessly small either
+            assert any(s == (6, 0, 6) or s[2] == 6 for s in v["steps"]) or v["idle"], key  # the idle-wave loop's vmcnt(NDMA)
+    # the shipped build: same kernels, nothing spills at 2 waves per SIMD, and the forward sweeps are the builds
+    # without packed fp32 instructions (they do not execute beside the SIMD partner's MFMAs)
     asm = str(tmp_path / "sweep_bf16.s")
-    emit_asm(os.path.join(REPO, "diffudf_amd", "csrc", "dudf_sweep_bf16.hip"), asm)
+    emit_asm(src, asm)
     res = analyse_bf16(asm)
-    assert set(res) == {(0, 3), (0, 2), (0, 0), (1, 1), (1, 0), (2, 0), (3, 1), (3, 0),
-                        (4, 1), (4, 0), (5, 1), (5, 0), (6, 0), (7, 0), (8, 0)}           # + the Hessian-quad variants
-    for key, v in res.items():
-        assert v["scratch"] == 0, key
-        for dma, ops, n in v["steps"]:
-            assert n <= 2 * ops + dma, f"sweep_bf16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) with {ops} ops/step"
-        # the unrolled steps of a layer (the first entry also carries the first layer's prologue traffic)
-        kmin = min(s[1] for s in v["steps"] if s[0] == 6)
-        steady = [s for s in v["steps"] if s[0] == 6 and s[1] == kmin]
-        assert len(steady) >= 7, (key, v["steps"])
-        for dma, ops, n in steady:
-            assert n == 2 * ops + dma, (key, dma, ops, n)          # and not needlessly small either
-        assert any(s == (6, 0, 6) or s[2] == 6 for s in v["steps"]) or v["idle"], key     # the idle-wave loop's vmcnt(NDMA)
+    assert set(res) == keys
+    assert all(v["scratch"] == 0 for v in res.values())
+    txt = open(asm).read()
+    import re
+    for m in re.finditer(r"^_ZN\w*sweep_bf16_np_kernelILi256ELi0ELi\dE\w*:", txt, re.M):
+        body = txt[m.end():txt.index("s_endpgm", m.end())]
+        assert "v_pk_fma_f32" not in body and "v_pk_mul_f32" not in body and "v_pk_add_f32" not in body
+    assert len(re.findall(r"^_ZN\w*sweep_bf16_np_kernelILi256ELi0ELi\dE\w*:", txt, re.M)) == 3
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")

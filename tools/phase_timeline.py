@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Timeline of one workgroup's k-block steps in the four bf16 sweeps (timing experiment; needs a library built with
+-DDUDF_SWEEP_DBG=128, see tools/build_dbg.sh):   DUDF_LIB=dbg/libdudf_st.so python tools/phase_timeline.py
+Prints, per sweep and k-block of layer 3, the s_memtime stamps of waves 0 and 4 (SIMD partners) relative to wave 0's
+step start, in shader-clock cycles (s_memtime): top | feed done | tail start | tail end | MFMAs issued | DMA wait done."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from diffudf_amd import _lib, hip_ops, synth
+from diffudf_amd.engine import TrainEngine
+
+lib = _lib.load()
+hid = [256] * 8
+dev = torch.device("cuda:0")
+theta = torch.from_numpy(synth.flatten_params(synth.siren_params(hid, seed=123))).to(dev)
+x, nrm, sdf = [torch.from_numpy(a).to(dev) for a in synth.training_batch(100000, seed=123)]
+eng = TrainEngine(hid, theta)
+for _ in range(5):
+    eng.step(hip_ops.LOSS_S1, x, nrm, sdf.reshape(-1), [1e4, 1e4, 0.0, 1e3], 100.0, lr=1e-4, n_global=100000, n_hess=0)
+torch.cuda.synchronize()
+buf = np.zeros((4, 8, 8, 8), dtype=np.uint64)
+fn = lib.dudf_dbg_stamps
+fn.argtypes = [ctypes.c_void_p]
+rc = fn(buf.ctypes.data_as(ctypes.c_void_p))
+assert rc == 0, rc
+names = ["fwd", "rev", "adj_fwd", "adj_rev"]
+for s in range(4):
+    t0 = int(buf[s, 0, 0, 0])
+    print("== %s (cycles from wave 0's first step top; layer 3)" % names[s])
+    for kb in range(8):
+        for w in (0, 4, 1, 5):
+            st = [(int(v) - t0) * 10 if v else -1 for v in buf[s, w, kb]]
+            st = [v // 10 if v >= 0 else -1 for v in st]
+            print("  kb %d wave %d: top %6d feed %6d | tail %6d..%6d | mfma issued %6d | wait done %6d | mid feed %6d..%6d" % (kb, w, *st))
+    step = (int(buf[s, 0, 7, 0]) - t0) * 10 / 7.0
+    print("  mean step %.0f cycles" % (step / 10))
