@@ -102,6 +102,15 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     return 0;
 }
 
+// Kernels whose vector-ALU work should run BESIDE the SIMD partner's MFMAs are built without the packed fp32 instructions
+// (v_pk_fma_f32, v_pk_add_f32 ...): those occupy the matrix pipe's slot (tools/micro/coissue.hip — 48 of them + 24 MFMAs
+// take the sum of their times; the unpacked forms the maximum + 25 %).  Device pass only (the host pass has no such feature).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DUDF_NO_PK __attribute__((target("no-packed-fp32-ops")))
+#else
+#define DUDF_NO_PK
+#endif
+
 // ---- launchers implemented in the .hip translation units -------------------------------------
 struct SweepArgs {
     const float* theta; const float* w1b; const float* w1t16; const float* wt;

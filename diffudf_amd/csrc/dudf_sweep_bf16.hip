@@ -439,11 +439,6 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
 // 24 MFMAs take the SUM of their times, 48 v_fma_f32 + 24 MFMAs the maximum + 25 %).  The forward sweep, whose sin/cos
 // tail is as long as its MFMA stream, is therefore built WITHOUT them and overlaps the two; the other sweeps (short
 // tails, bound by the stash stream) keep them.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DUDF_NO_PK __attribute__((target("no-packed-fp32-ops")))
-#else
-#define DUDF_NO_PK
-#endif
 template <int SW> constexpr bool sweep_no_pk() { return SW == SWEEP_FWD; }
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
 #define DUDF_WGRAD_DBG 0           // timing experiments only (wrong results): 1 no loads, 2 no barrier, 4 no MFMA, 8 no split,
 #endif                             // 16 no LDS fragment reads
 template <int H, int VAR>
-__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     using W = WG<H>;
     static_assert(H == 256, "256 x 256 output tiles");
     constexpr int NW_ = W::WO * W::WI;
@@ -529,9 +529,6 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
         if (nit > 3) load_raw_plain(3, R0);
     }
     __syncthreads();
-    // VAR bit 3: the two waves of a SIMD (w, w + 4) run slice and MFMA group in OPPOSITE order, so that one's slice (vector
-    // ALU) falls beside the other's MFMAs instead of both splitting and then both multiplying
-    const bool late = (VAR & 8) != 0 && __builtin_amdgcn_readfirstlane((int)(wave >= NW_ / 2)) != 0;
     // one stage: the next stage's registers -> pieces (its set is then refilled with the stage three further on, so three
     // stages = 96 KiB per CU stay in flight: with one, the kernel measured latency-bound at 2 TB/s), then 48 MFMAs
     auto stage = [&](int it, RawSet& r, auto hot) {
@@ -569,7 +566,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
                 for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n, pc);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (HOT && !(DBG & 1)) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
-                if constexpr (!(DBG & 8)) { if (more && !late) split_slice(it + 1, r, n); }
+                if constexpr (!(DBG & 8)) { if (more) split_slice(it + 1, r, n); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
@@ -593,10 +590,6 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
                 acc[m][n] = c;
             }
             if constexpr (IL) __builtin_amdgcn_sched_barrier(0);
-            if constexpr (IL && (VAR & 8) != 0 && !(DBG & 8)) {       // waves 4-7: this group's slice BEHIND its MFMAs
-                if (more && late) split_slice(it + 1, r, n);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         if constexpr (IL) {
             if constexpr (HOT) { if constexpr (!(DBG & 1)) load_raw(it + 4, r); }
@@ -656,6 +649,13 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16p
         }
     }
 }
+// built without packed fp32 instructions (dudf_internal.h, DUDF_NO_PK): the split slices of one wave then execute beside its
+// SIMD partner's MFMAs (-5 % on this kernel).  The body is a forced-inline function: lambdas defined inside a function
+// that carries the target attribute do not inherit it and would not be inlined.
+template <int H, int VAR>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_bf16p_kernel(WgradArgs a) {
+    wgrad_hidden_bf16p_body<H, VAR>(a);
+}
 
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
 //   dW_1[o][d] | db_1[o] = sum_c  q_1[o][c] * gbar[c][d]  +  zbar_1[o][c] * x4[c][d]      (d = 3 is the bias: x4[c][3])
@@ -678,7 +678,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // grid.x = column ranges, grid.y = feature-quad groups; block = 256 threads = 4 waves; each wave loops over
 // feature quads, lanes run over 64 consecutive columns (16-byte granules -> 1 KiB coalesced per load).
-__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
+__device__ __forceinline__ void wgrad_small_body(const WgradSmallArgs& a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int FQ = a.H / 4;
     const int64_t p0 = (int64_t)blockIdx.x * a.pts_per_block;
@@ -733,6 +733,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
         if (lane == 0) atomicAdd(a.dtheta + a.off_bo, s);
     }
 }
+__global__ __launch_bounds__(256) DUDF_NO_PK void wgrad_small_kernel(WgradSmallArgs a) { wgrad_small_body(a); }
 
 template <int H>
 int launch_hidden(const WgradArgs& a, hipStream_t st) {
@@ -777,16 +778,15 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                 }
                 // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7} (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split,
                 // bit 2 static priority for waves 0-3 (stagger)
-                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 3; }();
+                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 7 : 3; }();
                 if (!attr3) {
                     hipError_t e = hipSuccess;
-                    const void* fns[6] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
+                    const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 5>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 11>)};
-                    for (int v = 0; v < 6 && e == hipSuccess; ++v)
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>)};
+                    for (int v = 0; v < 5 && e == hipSuccess; ++v)
                         e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
@@ -798,7 +798,6 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     case 3: DUDF_WG_GO(3); break;
                     case 5: DUDF_WG_GO(5); break;
                     case 7: DUDF_WG_GO(7); break;
-                    case 11: DUDF_WG_GO(11); break;
                     default: DUDF_WG_GO(3); break;
                 }
 #undef DUDF_WG_GO
