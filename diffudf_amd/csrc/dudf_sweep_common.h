@@ -37,10 +37,9 @@ __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2&
     const dudf_f2 cr = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (dudf_f2)(-0.5f), (dudf_f2)(1.0f)));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float sa = (n[i] & 1) ? cr[i] : sr[i];
-        const float ca = (n[i] & 1) ? sr[i] : cr[i];
-        s_out[i] = (n[i] & 2) ? -sa : sa;
-        c_out[i] = ((n[i] + 1) & 2) ? -ca : ca;
+        float so, co;
+        dudf_quadrant(n[i], sr[i], cr[i], &so, &co);
+        s_out[i] = so; c_out[i] = co;
     }
 }
 
