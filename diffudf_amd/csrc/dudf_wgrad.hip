@@ -394,9 +394,20 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
 // VAR bit 1: the split of the next stage is cut into four feature slices issued BETWEEN the four MFMA groups of this
 //   stage instead of in front of them: the two waves of a SIMD then leave the post-barrier lockstep (both splitting,
 //   matrix core idle) after the first slice — one wave's slice runs beside the other's MFMAs.
+#ifndef DUDF_WG_HREL
+#define DUDF_WG_HREL 2             // flag-synchronised variant: hand the matrix pipe over this many MFMA groups before the end of a stage
+#endif
 #ifndef DUDF_WGRAD_DBG
 #define DUDF_WGRAD_DBG 0           // timing experiments only (wrong results): 1 no loads, 2 no barrier, 4 no MFMA, 8 no split,
 #endif                             // 16 no LDS fragment reads
+#if DUDF_WGRAD_DBG & 32
+// phase stamps of the LAST steady-state stage of one workgroup (timing experiments): [wave][stamp], shader-clock cycles
+__device__ unsigned long long g_wstamp[8][12];
+extern "C" int dudf_dbg_wstamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), sizeof(g_wstamp)); }
+#define DUDF_WSTAMP(i) do { if constexpr (HOT) { __builtin_amdgcn_sched_barrier(0); wst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define DUDF_WSTAMP(i) do { } while (0)
+#endif
 template <int H, int VAR>
 __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     using W = WG<H>;
@@ -483,8 +494,43 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     auto wait_raw = [&](RawSet& r, auto younger) {       // this set has landed; `younger` loads issued after it stay in flight
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.g0), "+v"(r.g1), "+v"(r.g2), "+v"(r.g3) : "n"(decltype(younger)::value));
     };
-    auto split_slice = [&](int it, const RawSet& r, int f) {              // feature f of the lane's quad -> piece image buffer it & 1
-        char* dst = ldsb + (it & 1) * BUFB + p_loff + 16 * f;
+    // VAR bit 3: THREE image buffers and per-buffer counters in LDS instead of the workgroup barrier of every stage: a wave
+    // starts stage `it` when all eight waves have written their part of image `it` (counter W) and have finished reading
+    // the buffer its own slices are about to overwrite (counter R, image it - 2): waves may drift up to a stage apart, so the
+    // SIMD partner that the issue arbitration serves first (the older wave) no longer idles a third of every stage at the
+    // barrier while the younger one finishes.
+    constexpr bool CS = (VAR & 8) != 0;
+    // Per-wave progress words in LDS (no atomics, no address registers).  A wave publishes with ds_write_addtid_b32 from lane 0
+    // (address M0) and polls the whole block with one ds_read_addtid_b32 (lane i reads word i).  Inline asm: the poll is a
+    // loop, and a compiler-visible loop inside the hand-counted stage loop makes hipcc spill registers that still have loads
+    // in flight.
+    const unsigned flag0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(ldsb + 3 * BUFB);
+    auto publish = [&](unsigned lds_addr, unsigned value) {
+        unsigned keep, vt; uint64_t ex;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %2, exec\n\ts_mov_b64 exec, 1\n\t"
+                     "v_mov_b32 %1, %4\n\tds_write_addtid_b32 %1\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(vt), "=&s"(ex) : "s"(lds_addr), "s"(value) : "memory");
+    };
+    // one block of 24 words: lanes 0-7 = images written by waves 0..7, 8-15 = stages whose fragment reads are finished,
+    // 16-23 = stages whose MFMAs are nearly all issued.  All three are plain stage counters.
+    auto poll = [&](unsigned need_w, unsigned need_r, unsigned need_h03, unsigned need_h47) {
+        unsigned keep, vt, t0, t1;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n"
+                     ".Ldudf_poll%=:\n\t"
+                     "ds_read_addtid_b32 %1\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_cmp_le_u32 vcc, %5, %1\n\ts_and_b32 %2, vcc_lo, 0xff\n\t"
+                     "v_cmp_le_u32 vcc, %6, %1\n\ts_and_b32 %3, vcc_lo, 0xff00\n\ts_or_b32 %2, %2, %3\n\t"
+                     "v_cmp_le_u32 vcc, %7, %1\n\ts_and_b32 %3, vcc_lo, 0xf0000\n\ts_or_b32 %2, %2, %3\n\t"
+                     "v_cmp_le_u32 vcc, %8, %1\n\ts_and_b32 %3, vcc_lo, 0xf00000\n\ts_or_b32 %2, %2, %3\n\t"
+                     "s_cmp_eq_u32 %2, 0xffffff\n\t"
+                     "s_cbranch_scc1 .Ldudf_done%=\n\ts_sleep 1\n\ts_branch .Ldudf_poll%=\n"
+                     ".Ldudf_done%=:\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(vt), "=&s"(t0), "=&s"(t1)
+                     : "s"(flag0), "s"(need_w), "s"(need_r), "s"(need_h03), "s"(need_h47) : "memory", "vcc", "scc");
+    };
+    auto split_slice = [&](int it, const RawSet& r, int f, int bsel) {    // feature f of the lane's quad -> piece image buffer bsel
+        char* dst = ldsb + bsel * BUFB + p_loff + 16 * f;
         if (f == 0) {
             // Hessian quads: only columns % 4 == 0 (the value channel) carry the bias — all four granules of the lanes
             // with p_cg == 0, none of the others
@@ -506,9 +552,9 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         *reinterpret_cast<u32x2*>(dst + PIECEB) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(dst + 2 * PIECEB) = u32x2{l0, l1};
     };
-    auto split_store = [&](int it, const RawSet& r) {                     // raw (stage it) -> piece image buffer it & 1
+    auto split_store = [&](int it, const RawSet& r, int bsel) {           // raw (stage it) -> piece image buffer bsel
 #pragma unroll
-        for (int f = 0; f < 4; ++f) split_slice(it, r, f);
+        for (int f = 0; f < 4; ++f) split_slice(it, r, f, bsel);
     };
     // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
     const int c_lane = (lane >> 5) * HALFB + (lane & 31) * 16;
@@ -521,9 +567,27 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         return *reinterpret_cast<const bf16x8*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
     };
 
-    if (nit > 0) {
+    if constexpr (CS) {
+        if (tid < 128) reinterpret_cast<unsigned*>(ldsb + 3 * BUFB)[tid] = 0;
+        __syncthreads();
+    }
+    if constexpr (CS) {                                  // images 0 and 1 written, images 2, 3, 4 in flight (image k: set k % 3)
+        if (nit > 0) {
+            load_raw_plain(0, R0);
+            if (nit > 1) load_raw_plain(1, R1);
+            if (nit > 2) load_raw_plain(2, R2);
+            split_store(0, R0, 0);
+            publish(flag0 + 4u * (unsigned)wave, 1u);                          // one image written
+            if (nit > 3) load_raw_plain(3, R0);
+            if (nit > 1) {
+                split_store(1, R1, 1);
+                publish(flag0 + 4u * (unsigned)wave, 2u);                      // two
+            }
+            if (nit > 4) load_raw_plain(4, R1);
+        }
+    } else if (nit > 0) {
         load_raw_plain(0, R0);
-        split_store(0, R0);
+        split_store(0, R0, 0);
         if (nit > 1) load_raw_plain(1, R1);
         if (nit > 2) load_raw_plain(2, R2);
         if (nit > 3) load_raw_plain(3, R0);
@@ -531,20 +595,37 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     __syncthreads();
     // one stage: the next stage's registers -> pieces (its set is then refilled with the stage three further on, so three
     // stages = 96 KiB per CU stay in flight: with one, the kernel measured latency-bound at 2 TB/s), then 48 MFMAs
-    auto stage = [&](int it, RawSet& r, auto hot) {
-        const char* buf = ldsb + (it & 1) * BUFB;
+    unsigned long long wst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stage = [&](int it, RawSet& r, auto hot, auto bidx) {
+        constexpr int BI = decltype(bidx)::value;             // it % 3 (the loops advance by three stages)
+        const int bcur = CS ? BI : (it & 1), bnext = CS ? (BI + 1) % 3 : ((it + 1) & 1);
+        const char* buf = ldsb + bcur * BUFB;
         constexpr bool HOT = decltype(hot)::value;
+        DUDF_WSTAMP(0);
+        if constexpr (CS) {
+            // every wave has written its part of image `it` (generation g + 1 of W[BI]) and has finished reading image
+            // it - 1, whose buffer this wave's split of image it + 2 is going to overwrite (R[(BI + 2) % 3])
+            // (the second condition is checked in front of the split, behind this stage's MFMAs: the SIMD partner runs half
+            //  a stage behind, and waiting for ITS reads here would stall this wave at the top of every stage)
+            // + the SIMD partners alternate on the matrix pipe: waves 4-7 start the MFMAs of stage `it` when waves 0-3 have
+            //   issued most of theirs, waves 0-3 start stage `it` when waves 4-7 have issued most of stage it - 1 (the flag is
+            //   raised one MFMA group before the end, so that the hand-over latency is covered)
+            const unsigned uit = (unsigned)it;
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(wave >= NW_ / 2));
+            poll(uit + 1u, 0u, hi ? uit + 1u : 0u, hi ? 0u : uit);
+        }
         constexpr int DBG = HOT ? DUDF_WGRAD_DBG : 0;
         constexpr bool IL = (VAR & 2) != 0;
         static_assert(!IL || W::NTL == 4, "one split slice per MFMA group");
+        static_assert(!(CS && IL), "the flag-synchronised variant multiplies first and splits two images ahead");
         const bool more = HOT || it + 1 < nit;
-        if constexpr (!IL) {
+        if constexpr (!IL && !CS) {
             if constexpr (HOT) {                  // steady state: the two younger sets (8 loads) stay in flight
                 wait_raw(r, std::integral_constant<int, 8>{});
-                split_store(it + 1, r);
+                split_store(it + 1, r, bnext);
                 load_raw(it + 4, r);
             } else if (more) {
-                split_store(it + 1, r);
+                split_store(it + 1, r, bnext);
                 if (it + 4 < nit) load_raw_plain(it + 4, r);
             }
         }
@@ -553,6 +634,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         for (int m = 0; m < W::MT; ++m)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) af[m][pc] = fragA(buf, m, pc);
+        DUDF_WSTAMP(1);
         if constexpr (!IL) {
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, 0, pc);
@@ -566,8 +648,9 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                 for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n, pc);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (HOT && !(DBG & 1)) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
-                if constexpr (!(DBG & 8)) { if (more) split_slice(it + 1, r, n); }
+                if constexpr (!(DBG & 8)) { if (more) split_slice(it + 1, r, n, bnext); }
                 __builtin_amdgcn_sched_barrier(0);
+                DUDF_WSTAMP(2 + 2 * n);
             }
             const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
             if constexpr (!IL) {
@@ -590,12 +673,40 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                 acc[m][n] = c;
             }
             if constexpr (IL) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CS) {
+                if (n == W::NTL - DUDF_WG_HREL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    publish(flag0 + 64u + 4u * (unsigned)wave, (unsigned)it + 1u);                 // nearly done with the matrix pipe
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            DUDF_WSTAMP(3 + 2 * n);
         }
         if constexpr (IL) {
             if constexpr (HOT) { if constexpr (!(DBG & 1)) load_raw(it + 4, r); }
             else if (it + 4 < nit) load_raw_plain(it + 4, r);
         }
-        if constexpr (!(DBG & 2)) __syncthreads();
+        if constexpr (CS) {
+            // behind this stage's last fragment reads (LDS executes a wave's operations in order): image `it` read; then
+            // the split of image it + 2 into the buffer image it - 1 lived in, and its flag
+            __builtin_amdgcn_sched_barrier(0);
+            publish(flag0 + 32u + 4u * (unsigned)wave, (unsigned)it + 1u);                       // fragment reads of stage `it` done
+            constexpr int BW = (BI + 2) % 3;
+            if (HOT || it + 2 < nit) poll(0u, (unsigned)it, 0u, 0u);                             // image it - 1 read by everybody: its buffer is free
+            if constexpr (HOT) {
+                wait_raw(r, std::integral_constant<int, 8>{});
+                split_store(it + 2, r, BW);
+                load_raw(it + 5, r);
+                publish(flag0 + 4u * (unsigned)wave, (unsigned)it + 3u);                         // images 0 .. it + 2 written
+            } else if (it + 2 < nit) {
+                split_store(it + 2, r, BW);
+                if (it + 5 < nit) load_raw_plain(it + 5, r);
+                publish(flag0 + 4u * (unsigned)wave, (unsigned)it + 3u);
+            }
+        }
+        DUDF_WSTAMP(10);
+        if constexpr (!(DBG & 2) && !CS) __syncthreads();
+        DUDF_WSTAMP(11);
     };
     // VAR bit 2: static priority for waves 0-3 (their SIMD partners are waves 4-7).  Both waves of a SIMD leave every
     // barrier in lockstep, so their split slices (VALU, matrix core idle) and their MFMA groups (matrix core contended)
@@ -603,7 +714,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     // falls behind by one slice and from then on runs its slices beside the partner's MFMAs.  No per-stage flips.
     if constexpr ((VAR & 4) != 0) { if (wave < NW_ / 2) __builtin_amdgcn_s_setprio(1); }
     int it = 0;                                                  // stage it+1 lives in set (it+1) % 3
-    const int nhot = nit >= 7 ? ((nit - 4) / 3) * 3 : 0;
+    const int nhot = CS ? (nit >= 8 ? ((nit - 5) / 3) * 3 : 0) : (nit >= 7 ? ((nit - 4) / 3) * 3 : 0);
     // hipcc does not know the sets are in flight: enter (and leave) the hand-counted loop with everything landed, so that
     // the register copies it places on the loop's edges are harmless; inside, the sets stay put (tests/isa_contract.py
     // replays the loop body twice and fails on any instruction that touches a register with a load in flight)
@@ -612,17 +723,24 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                      "+v"(R1.g2), "+v"(R1.g3), "+v"(R2.g0), "+v"(R2.g1), "+v"(R2.g2), "+v"(R2.g3));
     };
     drain();
+    using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>; using B2 = std::integral_constant<int, 2>;
+    // register set of a stage: the image it splits — it + 1 (set (it + 1) % 3), or it + 2 with the flags (set (it + 2) % 3)
+    RawSet& Sa = CS ? R2 : R1; RawSet& Sb = CS ? R0 : R2; RawSet& Sc = CS ? R1 : R0;
     for (; it < nhot; it += 3) {
-        stage(it, R1, std::true_type{});
-        stage(it + 1, R2, std::true_type{});
-        stage(it + 2, R0, std::true_type{});
+        stage(it, Sa, std::true_type{}, B0{});
+        stage(it + 1, Sb, std::true_type{}, B1{});
+        stage(it + 2, Sc, std::true_type{}, B2{});
     }
     drain();
     for (; it < nit; it += 3) {
-        stage(it, R1, std::false_type{});
-        if (it + 1 < nit) stage(it + 1, R2, std::false_type{});
-        if (it + 2 < nit) stage(it + 2, R0, std::false_type{});
+        stage(it, Sa, std::false_type{}, B0{});
+        if (it + 1 < nit) stage(it + 1, Sb, std::false_type{}, B1{});
+        if (it + 2 < nit) stage(it + 2, Sc, std::false_type{}, B2{});
     }
+#if DUDF_WGRAD_DBG & 32
+    if (blockIdx.x == 3 && blockIdx.y == 10 && lane == 0)
+        for (int i = 0; i < 12; ++i) g_wstamp[wave][i] = wst[i];
+#endif
 
     float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)o_off * a.Hs + i_off;
     float* dB = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)a.Hs * a.Hs + o_off;
@@ -776,18 +894,21 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_bf, st, a);   // per-wave split
                     return (int)hipGetLastError();
                 }
-                // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7} (A/B testing): bit 0 conflict-free producer lanes, bit 1 interleaved split,
-                // bit 2 static priority for waves 0-3 (stagger)
-                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 7 : 3; }();
+                // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7, 9} (A/B testing; 9 ships): bit 0 conflict-free producer lanes, bit 1 interleaved
+                // split, bit 2 static priority for waves 0-3, bit 3 progress flags in LDS instead of the stage barrier (three image
+                // buffers, MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe)
+                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 9; }();
                 if (!attr3) {
                     hipError_t e = hipSuccess;
-                    const void* fns[5] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
+                    const size_t smem_cs = smem_p / 2 * 3 + 512;                     // three buffers + the flags
+                    const void* fns[6] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 5>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>)};
-                    for (int v = 0; v < 5 && e == hipSuccess; ++v)
-                        e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>),
+                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 9>)};
+                    for (int v = 0; v < 6 && e == hipSuccess; ++v)
+                        e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(v == 5 ? smem_cs : smem_p));
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
                 }
@@ -798,7 +919,8 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     case 3: DUDF_WG_GO(3); break;
                     case 5: DUDF_WG_GO(5); break;
                     case 7: DUDF_WG_GO(7); break;
-                    default: DUDF_WG_GO(3); break;
+                    case 9: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a); break;
+                    default: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a); break;
                 }
 #undef DUDF_WG_GO
                 return (int)hipGetLastError();

@@ -21,12 +21,16 @@ for _ in range(5):
     eng.step(hip_ops.LOSS_S1, x, nrm, sdf.reshape(-1), [1e4, 1e4, 0.0, 1e3], 100.0, lr=1e-4, n_global=100000, n_hess=0)
 torch.cuda.synchronize()
 buf = np.zeros((4, 8, 8, 8), dtype=np.uint64)
-fn = lib.dudf_dbg_stamps
-fn.argtypes = [ctypes.c_void_p]
-rc = fn(buf.ctypes.data_as(ctypes.c_void_p))
-assert rc == 0, rc
 names = ["fwd", "rev", "adj_fwd", "adj_rev"]
-for s in range(4):
+try:
+    fn = lib.dudf_dbg_stamps
+    fn.argtypes = [ctypes.c_void_p]
+    rc = fn(buf.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    have_sweeps = True
+except AttributeError:
+    have_sweeps = False
+for s in range(4 if have_sweeps else 0):
     t0 = int(buf[s, 0, 0, 0])
     print("== %s (cycles from wave 0's first step top; layer 3)" % names[s])
     for kb in range(8):
@@ -36,3 +40,17 @@ for s in range(4):
             print("  kb %d wave %d: top %6d feed %6d | tail %6d..%6d | mfma issued %6d | wait done %6d | mid feed %6d..%6d" % (kb, w, *st))
     step = (int(buf[s, 0, 7, 0]) - t0) * 10 / 7.0
     print("  mean step %.0f cycles" % (step / 10))
+
+# weight-gradient kernel (library built with -DDUDF_WGRAD_DBG=32): last steady-state stage of one workgroup
+if hasattr(lib, "dudf_dbg_wstamps") or True:
+    try:
+        fnw = lib.dudf_dbg_wstamps
+        fnw.argtypes = [ctypes.c_void_p]
+        wb = np.zeros((8, 12), dtype=np.uint64)
+        assert fnw(wb.ctypes.data_as(ctypes.c_void_p)) == 0
+        t0 = int(wb[:, 0].min())
+        print("== wgrad_hidden, one stage (cycles): start | A frags issued | slice0 mfma0 | slice1 mfma1 | slice2 mfma2 | slice3 mfma3 | loads issued | barrier passed")
+        for w in range(8):
+            print("  wave %d: " % w + " ".join("%6d" % (int(v) - t0) for v in wb[w]))
+    except AttributeError:
+        pass
