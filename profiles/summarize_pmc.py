@@ -23,6 +23,8 @@ NAMES = {"<256, 0, 3>": "sweep_fwd", "<256, 1, 1>": "sweep_rev", "<256, 2, 0>": 
 
 
 def kname(k):
+    if "sweep_bf16_np_kernel" in k:
+        k = k.replace("sweep_bf16_np_kernel", "sweep_bf16_kernel")      # the forward sweeps: build without packed fp32 ops
     if "sweep_bf16_kernel" in k:
         sig = k.split("sweep_bf16_kernel")[1].split("(")[0]
         return NAMES.get(sig, "sweep" + sig)
