@@ -92,3 +92,58 @@ def extract_mesh_CAP(ndf, grad, resolution, threshold=0.008, device=None):
         return trimesh.Trimesh(v, f, process=False)
     except ImportError:
         return TriangleSoup(v, f)
+
+
+def extract_mesh_MESHUDF(df_values, normals, device, smooth_borders=False, luts=None, **kwargs):
+    """Reference src/render_mc.py:101-199 (`extract_mesh_MESHUDF`): the MeshUDF marching cubes over the (N, N, N) field and
+    its (N, N, N, 3) direction field (outputs of `extract_fields`; tensors or numpy arrays), vertices shifted to
+    [-1, 1]^3.  The extraction itself — the reference's Cython extension — is `diffudf_amd.marching_cubes.udf_mc_lewiner`
+    over the host C++ library (bit-identical vertices and faces, tests/test_meshudf.py); the Lewiner tables come from the
+    caller (`luts=`) or from the reference's own `_marching_cubes_lewiner_luts.py` on `sys.path`.
+    Returns (vertices, faces, mesh).  The reference then cleans the mesh with trimesh (`process`, duplicate / degenerate
+    faces, `fill_holes`, optional Laplacian smoothing of the border): done the same way when trimesh is importable;
+    without it the raw extraction is returned in a `TriangleSoup` (and `smooth_borders` is ignored)."""
+    from .marching_cubes import udf_mc_lewiner
+    d = df_values.detach().cpu().numpy() if torch.is_tensor(df_values) else np.asarray(df_values)
+    g = normals.detach().cpu().numpy() if torch.is_tensor(normals) else np.asarray(normals)
+    d = np.where(d < 0, 0, d).astype(np.float32)
+    N = d.shape[0]
+    voxel_size = 2.0 / (N - 1)
+    verts, faces, _, _ = udf_mc_lewiner(d, g.astype(np.float32), spacing=[voxel_size] * 3, avg_thresh=1.05, max_thresh=1.75, luts=luts)
+    verts = verts - 1                                   # voxel origin (-1, -1, -1)
+    if len(faces) == 0:
+        raise ValueError("Could not find surface in volume")
+    try:
+        import trimesh
+    except ImportError:
+        mesh = TriangleSoup(verts, faces)
+        return torch.from_numpy(np.ascontiguousarray(verts)).float(), torch.from_numpy(np.ascontiguousarray(faces)).long(), mesh
+    mesh = trimesh.Trimesh(verts, faces).process(validate=False)
+    mesh.remove_duplicate_faces(); mesh.remove_degenerate_faces(); mesh.fill_holes()
+    mesh2 = trimesh.Trimesh(mesh.vertices, mesh.faces)
+    nv, nf, it = 0, 0, 0
+    while (nv, nf) != (len(mesh2.vertices), len(mesh2.faces)) and it < 10:
+        mesh2 = mesh2.process(validate=False)
+        mesh2.remove_duplicate_faces(); mesh2.remove_degenerate_faces()
+        nv, nf = len(mesh2.vertices), len(mesh2.faces)
+        it += 1
+        mesh2 = trimesh.Trimesh(mesh2.vertices, mesh2.faces)
+    mesh = trimesh.Trimesh(mesh2.vertices, mesh2.faces)
+    if smooth_borders:
+        from collections import defaultdict
+        from scipy.sparse import coo_matrix
+        border = trimesh.grouping.group_rows(mesh.edges_sorted, require_count=1)
+        nb = defaultdict(list)
+        for u, v in mesh.edges_sorted[border]:
+            nb[u].append(v); nb[v].append(u)
+        bv = np.array(list(nb.keys()))
+        if len(bv) > 0:
+            pi, pj = [], []
+            for k, ns in enumerate(nb.values()):
+                for j in ns:
+                    pi.append(k); pj.append(j)
+            sp = coo_matrix((np.ones(len(pi)), (pi, pj)), shape=(len(bv), len(mesh.vertices)))
+            for _ in range(5):
+                avg = sp @ mesh.vertices / sp.sum(axis=1)
+                mesh.vertices[bv] = mesh.vertices[bv] + 0.3 * (np.asarray(avg) - mesh.vertices[bv])
+    return torch.tensor(mesh.vertices).float(), torch.tensor(mesh.faces).long(), mesh

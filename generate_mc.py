@@ -5,16 +5,17 @@ path covers: `extract_fields` (value + gradient on the N^3 grid) feeding the CAP
 
     python generate_mc.py <config.json>            keys as the reference's configs/mc_cfg.json
 
-algorithm 'cap' is built.  'meshudf' (the Lewiner-table marching cubes of
-src/marching_cubes) and 'siren' (skimage's marching cubes on an SDF) are outside it: they raise.  'both' — what
-train.py asks for with gt_mode 'tanh' — writes the CAP mesh (`*_CAP.obj`) and returns (None, meshCAP)."""
+algorithms 'cap' (on the device), 'meshudf' (row 4: the Lewiner-table marching cubes of
+src/marching_cubes as host C++; needs the reference's `_marching_cubes_lewiner_luts.py` on sys.path, e.g.
+`sys.path.append('src/marching_cubes')` in a reference checkout) and 'both' (what train.py asks for with gt_mode 'tanh').
+'siren' (skimage's marching cubes on an SDF) is outside the build: it raises."""
 import json
 import sys
 
 import torch
 
 from src.model import SIREN
-from src.render_mc import extract_fields, extract_mesh_CAP
+from src.render_mc import extract_fields, extract_mesh_CAP, extract_mesh_MESHUDF
 
 
 def generate_mc(model, gt_mode, device, N, output_path, alpha=None, algorithm='cap', from_file=None):
@@ -24,19 +25,30 @@ def generate_mc(model, gt_mode, device, N, output_path, alpha=None, algorithm='c
         model.load_state_dict(torch.load(from_file["model_path"], weights_only=True))
     dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
     model.to(dev)
-    if algorithm in ('cap', 'both'):
+    if algorithm in ('cap', 'both', 'meshudf'):
         u, g = extract_fields(model, torch.Tensor([[]]).to(dev), N, gt_mode, dev, alpha)
+        dot = output_path.rfind('.')
+        if algorithm == 'meshudf':
+            _, _, mesh = extract_mesh_MESHUDF(u, g, dev, smooth_borders=True)
+            mesh.export(output_path)
+            print(f'Saved to {output_path}')
+            return mesh
         mesh = extract_mesh_CAP(u, g, N)                       # device tensors straight through: no host round trip
         if algorithm == 'cap':
             mesh.export(output_path)
             print(f'Saved to {output_path}')
             return mesh
-        dot = output_path.rfind('.')
-        path_cap = output_path[:dot] + '_CAP' + output_path[dot:]
+        path_mu, path_cap = output_path[:dot] + '_MU' + output_path[dot:], output_path[:dot] + '_CAP' + output_path[dot:]
         mesh.export(path_cap)
-        print(f'Saved to {path_cap} (the MeshUDF half of algorithm "both" is not part of this build)')
-        return None, mesh
-    raise ValueError(f"algorithm '{algorithm}' is not part of this build (CAP-UDF extraction only: 'cap' / 'both')")
+        try:
+            _, _, mesh_mu = extract_mesh_MESHUDF(u, g, dev, smooth_borders=True)
+        except Exception as e:                                 # no look-up tables on sys.path: the CAP half is still written
+            print(f'Saved to {path_cap} (MeshUDF half skipped: {e})')
+            return None, mesh
+        mesh_mu.export(path_mu)
+        print(f'Saved to {path_mu}, {path_cap}')
+        return mesh_mu, mesh
+    raise ValueError(f"algorithm '{algorithm}' is not part of this build ('cap', 'meshudf', 'both')")
 
 
 if __name__ == "__main__":

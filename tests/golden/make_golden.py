@@ -234,6 +234,71 @@ def make_g9():
     np.savez_compressed(os.path.join(HERE, "g9_slice.npz"), **out)
 
 
+def meshudf_case(kind, n, seed):
+    """Analytic unsigned fields + direction fields (what `extract_fields` hands to the MeshUDF extraction: |f| and the
+    NEGATED normalised gradient), float32."""
+    ax = np.linspace(-1, 1, n)
+    A, B, C = np.meshgrid(ax, ax, ax, indexing="ij")
+    rng = np.random.default_rng(seed)
+    if kind == "sphere":
+        r = np.sqrt(A * A + B * B + C * C); sd = r - 0.6
+        g = np.stack([A, B, C], -1) / np.maximum(r, 1e-9)[..., None]
+    elif kind == "sheet":                                   # open surface that leaves the domain
+        ga = -0.45 * np.cos(3 * A) * np.cos(2 * B); gb = 0.30 * np.sin(3 * A) * np.sin(2 * B)
+        nrm = np.sqrt(ga * ga + gb * gb + 1); sd = (C - 0.15 * np.sin(3 * A) * np.cos(2 * B)) / nrm
+        g = np.stack([ga, gb, np.ones_like(ga)], -1) / nrm[..., None]
+    elif kind == "cap":                                     # surface with a boundary inside the domain
+        r = np.sqrt(A * A + B * B + C * C); sd = r - 0.7
+        g = np.stack([A, B, C], -1) / np.maximum(r, 1e-9)[..., None]
+        sd = np.where(C < -0.2, np.abs(sd) + (-0.2 - C), sd)
+    elif kind == "two":                                     # two spheres meeting: ambiguous Lewiner configurations
+        r1 = np.sqrt((A - 0.33) ** 2 + B * B + C * C); r2 = np.sqrt((A + 0.33) ** 2 + B * B + C * C)
+        s1, s2 = r1 - 0.36, r2 - 0.36
+        sd = np.minimum(s1, s2)
+        g1 = np.stack([A - 0.33, B, C], -1) / np.maximum(r1, 1e-9)[..., None]
+        g2 = np.stack([A + 0.33, B, C], -1) / np.maximum(r2, 1e-9)[..., None]
+        g = np.where((s1 < s2)[..., None], g1, g2)
+    elif kind == "noisy":                                   # unreliable gradients: the unsure / deferred queues
+        r = np.sqrt(A * A + B * B + C * C); sd = r - 0.55 + 0.04 * np.sin(9 * A) * np.sin(8 * B) * np.sin(7 * C)
+        g = np.stack([A, B, C], -1) / np.maximum(r, 1e-9)[..., None] + 0.25 * rng.standard_normal(A.shape + (3,))
+        g = g / np.linalg.norm(g, axis=-1, keepdims=True)
+    elif kind == "zeros":                                   # exact zeros in the field, zero gradients at 5 % of the points
+        r = np.sqrt(A * A + B * B + C * C); sd = r - 0.5
+        g = np.stack([A, B, C], -1) / np.maximum(r, 1e-9)[..., None]
+        sd = np.where(np.abs(sd) < 0.03, 0.0, sd)
+        g = np.where((rng.random(A.shape) < 0.05)[..., None], 0.0, g)
+    udf = np.abs(sd).astype(np.float32)
+    return udf, (-g * np.sign(sd)[..., None]).astype(np.float32)
+
+
+def make_g10():
+    """MeshUDF marching cubes: the reference's own Cython extension, rebuilt from its sources where
+    they lie (oracle/build_ref.py -> oracle/_ref/), run through the reference's own wrapper `udf_mc_lewiner` on analytic
+    fields.  Inputs: field, direction field, and the look-up tables AS THE WRAPPER PASSES THEM to the extension (the
+    extension's `luts` argument, decoded by the reference's `_to_array`).  Outputs: vertices, faces, normals, values."""
+    sys.path.insert(0, REPO)
+    from oracle import build_ref
+    ref = build_ref.load()
+    assert ref is not None, "needs /root/reference and Cython"
+    import _marching_cubes_lewiner_luts as mcluts
+    out = {}
+    names = [n for n in dir(mcluts) if n.isupper() and isinstance(getattr(mcluts, n), tuple)]
+    for nme in names:
+        out["lut_" + nme] = ref._to_array(getattr(mcluts, nme)).copy()
+    for nme, arr in (("EDGESRELX", ref.EDGETORELATIVEPOSX), ("EDGESRELY", ref.EDGETORELATIVEPOSY), ("EDGESRELZ", ref.EDGETORELATIVEPOSZ)):
+        out["lut_" + nme] = np.asarray(arr, np.int8)
+    cases = [("sphere", 14, 0), ("sheet", 16, 0), ("cap", 18, 0), ("two", 20, 0), ("noisy", 17, 3), ("zeros", 19, 4), ("noisy", 24, 9)]
+    out["cases"] = np.array([f"{k}_{n}_{s}" for k, n, s in cases])
+    for k, n, s in cases:
+        udf, g = meshudf_case(k, n, s)
+        v, f, nn, val = ref.udf_mc_lewiner(udf, g, spacing=[2.0 / (n - 1)] * 3, avg_thresh=1.05, max_thresh=1.75)
+        tag = f"{k}_{n}_{s}"
+        out[tag + "_udf"] = udf; out[tag + "_grads"] = g
+        out[tag + "_vertices"] = v; out[tag + "_faces"] = f.astype(np.int32); out[tag + "_normals"] = nn; out[tag + "_values"] = val
+        print(tag, v.shape, f.shape)
+    np.savez_compressed(os.path.join(HERE, "g10_meshudf.npz"), **out)
+
+
 def main():
     # ---- G1: tiny net, everything stored --------------------------------------------------
     out = {}
@@ -357,5 +422,7 @@ if __name__ == "__main__":
         make_g8()
     elif sys.argv[1:] == ["g9"]:
         make_g9()
+    elif sys.argv[1:] == ["g10"]:
+        make_g10()
     else:
         main()
