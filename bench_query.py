@@ -66,6 +66,27 @@ def main():
                           "triangles": int(ff.shape[0]), "hbm_gb_s_algorithmic": 2 * 16 * N ** 3 / dt / 1e9,
                           "config": "BASELINE configs[4]: src/render_mc.py extract_mesh_CAP (count + scan + emit: the fields are "
                                     "read twice, 16 B per grid point each time)"}))
+    # config 5, MeshUDF variant (reference src/render_mc.py:101-134): the host C++ marching cubes on the same analytic sheet, at
+    # most 256^3 (serial by construction; the look-up tables are an ARGUMENT of the extraction — taken here from the test
+    # fixture that captured them at the reference's call boundary)
+    try:
+        from diffudf_amd import marching_cubes as mcu
+        g10 = np.load(os.path.join(REPO, "tests", "golden", "g10_meshudf.npz"))
+        luts = {k[4:]: g10[k] for k in g10.files if k.startswith("lut_")}
+        Nm = min(N, 256)
+        st = max(N // Nm, 1)
+        d_h = ndf_a[::st, ::st, ::st][:Nm, :Nm, :Nm].contiguous().cpu().numpy()
+        v_h = vec_a[::st, ::st, ::st][:Nm, :Nm, :Nm].contiguous().cpu().numpy()
+        t0 = time.perf_counter()
+        mv, mf, _, _ = mcu.udf_mc_lewiner(d_h, v_h, spacing=[2.0 / (Nm - 1)] * 3, luts=luts)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "MeshUDF marching cubes cells/sec (host C++17, one thread: pseudo-sign votes + breadth-first "
+                                    "flood + Lewiner tables; bit-identical to the reference's Cython extension)",
+                          "value": (Nm - 1) ** 3 / dt, "unit": "cells/s", "grid": Nm, "seconds": dt, "vertices": int(mv.shape[0]),
+                          "triangles": int(mf.shape[0]),
+                          "config": "BASELINE configs[4]: src/render_mc.py extract_mesh_MESHUDF (extraction only)"}))
+    except Exception as e:                                   # noqa: BLE001  (secondary measurement)
+        print(json.dumps({"metric": "MeshUDF marching cubes", "skipped": str(e)}))
     del ndf_a, vec_a
     M = args.rays ** 2
     x = torch.from_numpy(synth.training_batch(M, seed=5)[0]).cuda()
