@@ -894,31 +894,26 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_bf, st, a);   // per-wave split
                     return (int)hipGetLastError();
                 }
-                // DUDF_WGRAD_VAR in {0, 1, 3, 5, 7, 9} (A/B testing; 9 ships): bit 0 conflict-free producer lanes, bit 1 interleaved
-                // split, bit 2 static priority for waves 0-3, bit 3 progress flags in LDS instead of the stage barrier (three image
-                // buffers, MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe)
+                // DUDF_WGRAD_VAR in {1, 3, 9} (A/B testing; 9 ships): bit 0 conflict-free producer lanes (always on), bit 1 split
+                // interleaved with the MFMA groups, bit 3 progress flags in LDS instead of the stage barrier (three image buffers,
+                // MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe).  The plain producer-lane
+                // order and the static-priority variants (round-2 experiments, measured no faster) are no longer built.
                 static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 9; }();
                 if (!attr3) {
                     hipError_t e = hipSuccess;
                     const size_t smem_cs = smem_p / 2 * 3 + 512;                     // three buffers + the flags
-                    const void* fns[6] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 0>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
+                    const void* fns[3] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 5>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 7>),
                                           reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 9>)};
-                    for (int v = 0; v < 6 && e == hipSuccess; ++v)
-                        e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(v == 5 ? smem_cs : smem_p));
+                    for (int v = 0; v < 3 && e == hipSuccess; ++v)
+                        e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(v == 2 ? smem_cs : smem_p));
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
                 }
 #define DUDF_WG_GO(V) hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, V>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a)
                 switch (var) {
-                    case 0: DUDF_WG_GO(0); break;
                     case 1: DUDF_WG_GO(1); break;
                     case 3: DUDF_WG_GO(3); break;
-                    case 5: DUDF_WG_GO(5); break;
-                    case 7: DUDF_WG_GO(7); break;
                     case 9: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a); break;
                     default: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a); break;
                 }
