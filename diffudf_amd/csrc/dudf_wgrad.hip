@@ -595,7 +595,9 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     __syncthreads();
     // one stage: the next stage's registers -> pieces (its set is then refilled with the stage three further on, so three
     // stages = 96 KiB per CU stay in flight: with one, the kernel measured latency-bound at 2 TB/s), then 48 MFMAs
+#if DUDF_WGRAD_DBG & 32
     unsigned long long wst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto stage = [&](int it, RawSet& r, auto hot, auto bidx) {
         constexpr int BI = decltype(bidx)::value;             // it % 3 (the loops advance by three stages)
         const int bcur = CS ? BI : (it & 1), bnext = CS ? (BI + 1) % 3 : ((it + 1) & 1);
