@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Repeatability stress of the training backward (flag-synchronised weight-gradient kernel, staggered sweeps): the same
+batch many times, every result against the first one.  Float atomics move dtheta by ~1e-7 relative; a synchronisation
+race would show as an occasional large deviation.   python tools/stress_wgrad.py [repeats]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from diffudf_amd import hip_ops, synth
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+worst = 0.0
+for hidden, n, mode, w in (([256] * 8, 100000, hip_ops.LOSS_S1, [1e4, 1e4, 0.0, 1e3]), ([256] * 8, 29970, hip_ops.LOSS_S1, [1e4, 1e4, 1e4, 1e3]),
+                           ([256] * 8, 1000, hip_ops.LOSS_S1, [1e4, 1e4, 0.0, 1e3]), ([256] * 8, 130, hip_ops.LOSS_S1, [1e4, 1e4, 0.0, 1e3]),
+                           ([256] * 3, 4097, hip_ops.LOSS_S2, [1e4, 1e4, 0.0, 1e3]), ([512] * 4, 20000, hip_ops.LOSS_S1, [1e4, 1e4, 0.0, 1e3])):
+    cfg = hip_ops.make_cfg(hidden)
+    theta = torch.from_numpy(synth.flatten_params(synth.siren_params(hidden, seed=7))).cuda()
+    x, nrm, sdf = [torch.from_numpy(a).cuda() for a in synth.training_batch(n, seed=3)]
+    sdf = sdf.reshape(-1)
+    n_hess = int((sdf == 0).sum()) if w[2] != 0 else 0
+    ws = hip_ops.workspace_for(cfg, n, "cuda:0", n_hess=n_hess)
+    ref = None
+    dev = 0.0
+    for r in range(reps):
+        stats = None
+        if mode == hip_ops.LOSS_S2:
+            stats = hip_ops.s2_forward_stats(cfg, theta, x, sdf, ws)
+        else:
+            hip_ops.loss_forward(cfg, mode, theta, x, nrm, sdf, n, w, 100.0, ws, n_hess=n_hess)
+        g = hip_ops.loss_backward(cfg, mode, theta, x, nrm, sdf, n, w, 100.0, torch.ones(4, device="cuda:0"), stats, ws, n_hess=n_hess)
+        g = g.double()
+        if ref is None:
+            ref = g.clone()
+            assert torch.isfinite(ref).all()
+        else:
+            dev = max(dev, float((g - ref).abs().max() / ref.abs().max()))
+    print(f"hidden {hidden[0]}x{len(hidden)} n {n} mode {mode} n_hess {n_hess}: max deviation over {reps} repeats {dev:.2e}")
+    worst = max(worst, dev)
+assert worst < 2e-5, worst
+print("OK")
