@@ -68,8 +68,10 @@ class TrainEngine:
             self.terms.zero_()
             self.terms[:2] = ops.s2_terms(stats, weights)
         else:
-            terms = ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws, **kw)
-            self.terms.copy_(terms)
+            try:                                         # straight into the tail of the flat [dtheta | terms] buffer
+                ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws, out=self.terms, **kw)
+            except TypeError:                            # a backend without `out` (tests/test_distributed_gloo.py's stand-in)
+                self.terms.copy_(ops.loss_forward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, ws, **kw))
         if not overlapped:
             ops.loss_backward(self.cfg, mode, self.theta, x, normals, sdf, n_global, weights, alpha, self.ones,
                               stats, ws, dtheta=self.dtheta, **kw)

@@ -254,11 +254,12 @@ def _w4(weights):
     return (ctypes.c_double * 4)(*[float(v) for v in w])
 
 
-def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws, n_hess=0):
-    """n_hess > 0 (loss_s1 with a Hessian weight): the first n_hess points must be exactly the on-surface ones."""
+def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws, n_hess=0, out=None):
+    """n_hess > 0 (loss_s1 with a Hessian weight): the first n_hess points must be exactly the on-surface ones.
+    `out`: a contiguous float32 tensor of 4 to receive the terms (no extra copy kernel in the training loop)."""
     lib = _lib.load()
     n = x.shape[0]
-    terms = torch.empty(4, dtype=torch.float32, device=x.device)
+    terms = out if out is not None else torch.empty(4, dtype=torch.float32, device=x.device)
     rc = lib.dudf_loss_forward(ctypes.byref(cfg), mode, _ptr(theta), _ptr(x), _ptr(normals), _ptr(sdf), n,
                                int(n_global), int(n_hess), _w4(weights), float(alpha), _ptr(terms), _ptr(ws.buf),
                                ws.nbytes, _stream())
