@@ -265,10 +265,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // their tail (vector ALU) at the same time and then collide on the matrix pipe: the step costs tail + MFMAs of both.
     // Waves 4-7 therefore run their MFMAs FIRST and the tail of the next step behind them (the tail only needs the
     // previous layer's accumulators, not this step's): each half's tail falls beside the other half's MFMAs.
+    // (also for the Hessian-quad variants that keep their registers: the adjoint-forward quads and the jets would spill)
+    constexpr bool kLateOk = !HS || (SW != SWEEP_ADJ_FWD_H && SW != SWEEP_FWD_J);
     #ifdef DUDF_LATE_FORCE                                 // tests/isa_contract.py: one half's program order at a time, branch-free
-    const bool late = !HS && DUDF_LATE_FORCE;
+    const bool late = kLateOk && DUDF_LATE_FORCE;
 #else
-    const bool late = !HS && __builtin_amdgcn_readfirstlane((int)((a.prio & 4) == 0 && wave >= NWB / 2)) != 0;   // DUDF_SWEEP_PRIO=4: off (A/B)
+    const bool late = kLateOk && __builtin_amdgcn_readfirstlane((int)((a.prio & 4) == 0 && wave >= NWB / 2)) != 0;   // DUDF_SWEEP_PRIO=4: off (A/B)
 #endif
     // feed slot: after which tile's MFMAs a wave issues its DMA pieces and operand loads (-1: at the top of the step);
     // tail slot: after which tile's MFMAs it runs the tail of the next step.  A = waves 0-3, B = waves 4-7 (when `late`).
