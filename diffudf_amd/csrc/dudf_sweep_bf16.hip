@@ -441,7 +441,8 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
 // 24 MFMAs take the SUM of their times, 48 v_fma_f32 + 24 MFMAs the maximum + 25 %).  The forward sweep, whose sin/cos
 // tail is as long as its MFMA stream, is therefore built WITHOUT them and overlaps the two; the other sweeps (short
 // tails, bound by the stash stream) keep them.
-template <int SW> constexpr bool sweep_no_pk() { return SW == SWEEP_FWD; }
+// (the Hessian-quad and jet variants too: +3 % / +5 % on the Hessian-frame and curvature queries)
+template <int SW> constexpr bool sweep_no_pk() { return SW == SWEEP_FWD || SW >= SWEEP_FWD_H; }
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
 template <int H, int SW, int FL>
