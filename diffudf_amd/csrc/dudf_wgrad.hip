@@ -49,7 +49,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 template <int H>
-__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_hidden_body(const WgradArgs& a) {
     using W = WG<H>;
     constexpr int NTHR = 64 * W::WO * W::WI;
     constexpr int FQ = H / 4;                       // feature quads per operand
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_kerne
         }
     }
 }
+template <int H>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_kernel(WgradArgs a) { wgrad_hidden_body<H>(a); }   // no packed fp32: see dudf_internal.h
 
 // ---- the same GEMM on the bf16 matrix cores, at fp32 accuracy ("bf16x6") ---------------------------------------------
 // Every fp32 operand is split EXACTLY into three bf16 pieces v = h + m + l (8+8+8 significand bits); a product a*b is
@@ -240,7 +242,7 @@ constexpr int KB = 16;          // columns per stage of the bf16 kernel
 constexpr int NRING = 4;
 
 template <int H>
-__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_hidden_bf16_body(const WgradArgs& a) {
     using W = WG<H>;
     constexpr int NW_ = W::WO * W::WI;
     constexpr int FQ = H / 4;
@@ -378,6 +380,8 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) void wgrad_hidden_bf16_
         }
     }
 }
+template <int H>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_bf16_kernel(WgradArgs a) { wgrad_hidden_bf16_body<H>(a); }   // no packed fp32: see dudf_internal.h
 
 // ---- bf16x6 with a COOPERATIVE split (256 x 256 tiles) ----------------------------------------------------------------
 // The kernel above is bound by vector-ALU issue, not by the matrix cores: every wave splits the fragments it consumes, so
