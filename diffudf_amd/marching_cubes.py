@@ -24,13 +24,21 @@ LUT_NAMES = (
     "TILING13_3_", "TILING13_4", "TILING13_5_1", "TILING13_5_2", "TILING14",
     "TEST3", "TEST4", "TEST6", "TEST7", "TEST10", "TEST12", "TEST13", "SUBCONFIG13")      # = enum LutId in dudf_meshudf.cpp
 
-# edge index -> the two cube corners it joins, per axis (reference _marching_cubes_lewiner.py:157-159: geometry of the
-# cube numbering, not part of the Lewiner tables)
-EDGESREL = {
-    "EDGESRELX": np.array([[0, 1], [1, 1], [1, 0], [0, 0], [0, 1], [1, 1], [1, 0], [0, 0], [0, 0], [1, 1], [1, 1], [0, 0]], "int8"),
-    "EDGESRELY": np.array([[0, 0], [0, 1], [1, 1], [1, 0], [0, 0], [0, 1], [1, 1], [1, 0], [0, 0], [0, 0], [1, 1], [1, 1]], "int8"),
-    "EDGESRELZ": np.array([[0, 0], [0, 0], [0, 0], [0, 0], [1, 1], [1, 1], [1, 1], [1, 1], [0, 1], [0, 1], [0, 1], [0, 1]], "int8"),
-}
+def _edge_corner_tables():
+    """Edge index -> the (x, y, z) offsets of the two cube corners it joins, per axis, in the cube numbering the tables use
+    (`get_index_in_facelayer` sketch, reference .pyx:690-700): edges 0-3 walk the bottom ring (0,0) -> (1,0) -> (1,1) ->
+    (0,1) -> (0,0), edges 4-7 the same ring one level up, edges 8-11 are the verticals at the ring's corners."""
+    ring = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    ex, ey, ez = np.zeros((12, 2), "int8"), np.zeros((12, 2), "int8"), np.zeros((12, 2), "int8")
+    for i in range(4):
+        a, b = ring[i], ring[(i + 1) % 4]
+        for lvl in (0, 1):
+            ex[i + 4 * lvl], ey[i + 4 * lvl], ez[i + 4 * lvl] = (a[0], b[0]), (a[1], b[1]), (lvl, lvl)
+        ex[8 + i], ey[8 + i], ez[8 + i] = (a[0], a[0]), (a[1], a[1]), (0, 1)
+    return {"EDGESRELX": ex, "EDGESRELY": ey, "EDGESRELZ": ez}
+
+
+EDGESREL = _edge_corner_tables()
 
 _LIB = None
 
