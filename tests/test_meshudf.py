@@ -57,6 +57,27 @@ def test_mesh_properties_and_render_mc_mirror():
     assert abs(r.mean() - 0.6) < 0.02 and r.min() > 0.5 and r.max() < 0.7
 
 
+def test_closed_surfaces_come_out_watertight():
+    """size-independent property (no reference needed): random spheres -> closed 2-manifolds, vertices on the sphere"""
+    rng = np.random.default_rng(2)
+    for _ in range(12):
+        n = int(rng.integers(12, 40))
+        c = rng.uniform(-0.25, 0.25, 3); rad = rng.uniform(0.3, 0.6)
+        ax = np.linspace(-1, 1, n)
+        A, B, C = np.meshgrid(ax, ax, ax, indexing="ij")
+        r = np.sqrt((A - c[0]) ** 2 + (B - c[1]) ** 2 + (C - c[2]) ** 2)
+        sd = r - rad
+        g = np.stack([A - c[0], B - c[1], C - c[2]], -1) / np.maximum(r, 1e-9)[..., None]
+        v, f, _, _ = mc.udf_mc_lewiner(np.abs(sd).astype(np.float32), (-g * np.sign(sd)[..., None]).astype(np.float32),
+                                       spacing=[2.0 / (n - 1)] * 3, luts=LUTS)
+        e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+        _, counts = np.unique(e, axis=0, return_counts=True)
+        assert (counts == 2).all(), (n, rad)
+        assert len(v) - len(counts) + len(f) == 2
+        d = np.linalg.norm(v - 1 - c, axis=1)             # wrapper output is in [0, 2]^3 (z-y-x order = our array axes)
+        assert np.abs(d - rad).max() < 1.5 * (2.0 / (n - 1))
+
+
 def test_argument_checks_and_empty_field():
     with pytest.raises(ValueError):
         mc.udf_mc_lewiner(np.zeros((4, 4)), np.zeros((4, 4, 3)), luts=LUTS)
