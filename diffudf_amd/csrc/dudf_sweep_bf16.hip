@@ -696,6 +696,9 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         // read-back registers: `xa` carries the even k-blocks, `xb` the odd ones — the loop is unrolled by two so that a set
         // is never copied while its asm loads are in flight (a rolled loop would rotate them with v_mov at the back edge)
         f32x4 xa0, xa1, xb0, xb1;
+#if DUDF_SWEEP_DBG & 128
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
         ld_in(lin, 0, xa0, xa1);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa0), "+v"(xa1));      // k-block 0: nothing to overlap it with yet
         auto kstep = [&](int kb, f32x4& c0, f32x4& c1, f32x4& n0, f32x4& n1, auto steady) {
@@ -753,9 +756,22 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         // the last k-block's (dummy) read-back is still in flight and nothing will consume it: keep its registers until it
         // has landed, or hipcc hands them to the burst below while the load is still writing them
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa0), "+v"(xa1), "+v"(xb0), "+v"(xb1));
+#if DUDF_SWEEP_DBG & 128
+        const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+#endif
         tail_burst(in_layer(j + 1), j + 1 == nhid);
+#if DUDF_SWEEP_DBG & 128
+        const unsigned long long tw2 = __builtin_amdgcn_s_memtime();
+#endif
         dma_wait_b<0>();
         __syncthreads();
+#if DUDF_SWEEP_DBG & 128
+        if ((blockIdx.x == 100 || blockIdx.x == 101) && lane == 0 && (wave == 0 || wave == 4) && j < 8) {
+            const unsigned long long tw3 = __builtin_amdgcn_s_memtime();
+            unsigned long long* o = &g_stamp[SW & 3][(blockIdx.x - 100) * 2 + (wave >> 2)][j][0];
+            o[0] = tw0; o[1] = tw1; o[2] = tw2; o[3] = tw3;
+        }
+#endif
     }
     if constexpr (SW == SWEEP_FWD) {
         part += __shfl_xor(part, 16);
@@ -771,6 +787,15 @@ template <int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_w[];
     unsigned gc = 0;
+    // A/B knob (off by default): odd workgroups start (a.prio >> 8) x 1024 cycles late.  A layer of this kernel is a compute
+    // phase (the k-loop, 117 k cycles at 125 k points, matrix pipe 84 % busy) followed by a memory phase (the tail burst,
+    // 25-45 k cycles); putting the two halves of the chip half a layer out of step buys only 1.3 % on the step: the burst
+    // is bound by the CU's vector-memory instruction rate (8 waves x 5 wave-instructions per tile, ~20 cycles each), not
+    // by HBM (tools/phase_timeline_wide.py, -DDUDF_SWEEP_DBG=128).
+    if ((blockIdx.x & 1) && (a.prio >> 8) > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), dt = (unsigned long long)(a.prio >> 8) << 10;
+        while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+    }
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
