@@ -207,16 +207,23 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     __syncthreads();                                   // every wave is past its last LDS read of the previous tile
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte offset of the buffers
     const unsigned voff = (unsigned)lane * 16u;
-    dma_issue<H>(chunk_src(0), lds0 + gc * G::CHUNKB, voff, wave);
-    dma_issue<H>(chunk_src(1), lds0 + ((gc + 1) % 3) * G::CHUNKB, voff, wave);
+    // Waves 0-3 issue ALL the DMA pieces of a chunk (their own six and their SIMD partner's), waves 4-7 none: a
+    // vector-memory instruction stalls its wave's in-order issue for ~100 cycles when the CU's eight waves contend, and the
+    // waves that multiply first (4-7, see `late` below) are the ones the step waits for — their chain loses the six pieces,
+    // the other half, which idled at the barrier, takes them (-0.9 % on the step; the reverse assignment: no gain).
+    auto dma2 = [&](const char* src, unsigned dst) {
+        if (wave < NWB / 2) { dma_issue<H>(src, dst, voff, wave); dma_issue<H>(src, dst, voff, wave + NWB / 2); }
+    };
+    dma2(chunk_src(0), lds0 + gc * G::CHUNKB);
+    dma2(chunk_src(1), lds0 + ((gc + 1) % 3) * G::CHUNKB);
     if (wave >= nact) {                                // same DMA pieces, same barriers, nothing else
         dma_wait_b<0>();
         __syncthreads();
         for (int c = 0; c < total; ++c) {
             const bool more = c + 2 < total;
-            if (more) dma_issue<H>(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB, voff, wave);
+            if (more) dma2(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB);
             gc = (gc + 1) % 3;
-            if (more) dma_wait_b<G::NDMA>();           // only this step's pieces may still be in flight
+            if (more) dma_wait_b<2 * G::NDMA>();       // only this step's pieces may still be in flight (waves 4-7: nothing)
             else dma_wait_b<0>();
             __syncthreads();
         }
@@ -302,7 +309,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 else load_ops(lnx, kb + 2 - G::NKB, o);
             };
             auto feed = [&]() {                                      // this step's DMA pieces, then the operand loads
-                if (more) dma_issue<H>(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB, voff, wave);
+                if (more) dma2(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB);
                 if constexpr (!HS) load_after_next(ops_n1);          // one full step ahead
             };
             if ((FA < 0 && !late) || (FB < 0 && late)) feed();
@@ -369,7 +376,9 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             gc = (gc + 1) % 3;
             DUDF_STAMP(4);
 #if !(DUDF_SWEEP_DBG & 8)
-            if (more) dma_wait_b<2 * kYoung + G::NDMA>();               // chunk c+1 landed; c+2 and two steps' stash traffic stay in flight
+            // chunk c+1 landed; c+2 and two steps' stash traffic stay in flight.  Only the waves that issued DMA pieces wait
+            // (0-3: the barrier behind publishes the chunk to the others)
+            if (more) { if (wave < NWB / 2) dma_wait_b<2 * kYoung + 2 * G::NDMA>(); }
             else dma_wait_b<0>();
 #endif
             DUDF_STAMP(5);
