@@ -34,7 +34,7 @@ for s in range(4 if have_sweeps else 0):
     t0 = int(buf[s, 0, 0, 0])
     print("== %s (cycles from wave 0's first step top; layer 3)" % names[s])
     for kb in range(8):
-        for w in (0, 4, 1, 5):
+        for w in ((0, 4, 1, 5) if os.environ.get("DUDF_TL_ALL") is None else range(8)):
             st = [(int(v) - t0) * 10 if v else -1 for v in buf[s, w, kb]]
             st = [v // 10 if v >= 0 else -1 for v in st]
             print("  kb %d wave %d: top %6d feed %6d | tail %6d..%6d | mfma issued %6d | wait done %6d | mid feed %6d..%6d" % (kb, w, *st))
