@@ -16,12 +16,19 @@ from . import hip_ops
 from ._lib import DudfError
 
 
+# Operations that only re-shape / re-type / copy a tensor: the result is still the same field, point for point.
+_SHAPE_ONLY = {"squeeze", "unsqueeze", "reshape", "view", "view_as", "reshape_as", "flatten", "unflatten", "contiguous",
+               "detach", "clone", "float", "to", "type", "__getitem__", "select"}
+
+
 class FieldTensor(torch.Tensor):
     """What `SIREN.forward` returns as 'model_out' and what `gradient` / `compute_normals_and_cd` return: an ordinary
     tensor that remembers WHICH field of the network it is (`_dudf_kind`: 'value', 'grad', 'eig_normal') and hands
-    that on — prefixed with 'from:' — to anything computed from it.  The reference's operators take (y, x) pairs of an
-    autograd graph; here the pair has to name a field the kernels can evaluate, and a tensor derived from one (a
-    squeezed output, but also a slice of a gradient) must not be mistaken for another."""
+    that on to anything computed from it — as 'view:<field>' through shape-only operations (squeeze, reshape, view,
+    detach, clone ...: still the same numbers per point), as 'fn:<field>' through everything else (2 * y, tanh(y),
+    y.abs(), a sum with another tensor ...).  The reference's operators take (y, x) pairs of an autograd graph; here
+    the pair has to name a field the kernels can evaluate, and a FUNCTION of one must fail loudly instead of being
+    mistaken for it (round-2 advice: `gradient(2 * y, x)` silently returned grad f)."""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -30,7 +37,9 @@ class FieldTensor(torch.Tensor):
         for a in args:
             k = getattr(a, "_dudf_kind", None) if isinstance(a, torch.Tensor) else None
             if k is not None:
-                kind = k if k.startswith("from:") else "from:" + k
+                base = k.split(":", 1)[-1]
+                shape_only = getattr(func, "__name__", "") in _SHAPE_ONLY and not k.startswith("fn:")
+                kind = ("view:" if shape_only else "fn:") + base
                 break
         if kind is not None:
             for o in (out if isinstance(out, (tuple, list)) else (out,)):
@@ -67,20 +76,21 @@ def _source(y, x):
 
 
 def _kind(y, coords):
-    """What field of the network `y` is.  Tagged results keep their tag; a tensor computed FROM the model output that
-    still has one value per point (squeeze / reshape / view, e.g. reference src/loss_functions.py:141) is the model
-    output; everything else has no HIP path."""
+    """What field of the network `y` is.  Tagged results keep their tag; a tensor obtained from the model output through
+    shape-only operations that still has one value per point (squeeze / reshape / view, e.g. reference
+    src/loss_functions.py:141) IS the model output; a function of a field (2 * y, tanh(y), a slice of a gradient) has
+    no HIP path and raises."""
     k = getattr(y, "_dudf_kind", None)
     n = coords.numel() // 3
     if k in ("value", "grad", "eig_normal"):
         return k
-    if k == "from:value" and y.numel() == n:
+    if k == "view:value" and y.numel() == n:
         return "value"
     if k is None:
         raise DudfError("this tensor does not come from diffudf_amd.model.SIREN.forward (generic autograd graphs have no "
                         "HIP path here)")
-    raise DudfError(f"no HIP path for a tensor derived from the '{k[5:]}' field (slices of a gradient: use hessian(y, x); "
-                    "arbitrary functions of the output: use fields())")
+    raise DudfError(f"no HIP path for a tensor derived from the '{k.split(':', 1)[-1]}' field (slices of a gradient: use "
+                    "hessian(y, x); arbitrary functions of the output: use fields())")
 
 
 class _InputGradient(torch.autograd.Function):
@@ -124,7 +134,7 @@ def gradient(y, x, grad_outputs=None):
         g = g.reshape(coords.shape)
     if grad_outputs is not None:
         g = g * grad_outputs.reshape(coords.shape[:-1] + (1,))
-        return tag_field(g, "from:grad")
+        return tag_field(g, "fn:grad")
     return tag_field(g, "grad")                        # divergence(gradient(y, x), x) finds its way (laplace)
 
 
@@ -132,6 +142,8 @@ def hessian(y, x):
     """(1,N,3,3) like reference src/diff_operators.py:187-193: row i = grad(df/dx_i, x).  Forward-over-reverse in
     the kernels (three tangent columns per point), not repeated autograd.  Plain tensor, like `gradient`."""
     model, coords = _source(y, x)
+    if _kind(y, coords) != "value":
+        raise DudfError("hessian(y, x): `y` must be the model output")
     x2 = coords.detach().reshape(-1, 3)
     _, _, h = hip_ops.query_hessian(model.hip_cfg, model.flat_parameters(), x2)
     return h.reshape(coords.shape[:-1] + (3, 3)) if coords.dim() == 3 else h.unsqueeze(0)
@@ -166,11 +178,12 @@ def jacobian(y, x):
     the result holds a NaN, as in the reference."""
     import torch
     model, coords = _source(y, x)
+    kind = _kind(y, coords)
     x2 = coords.detach().reshape(-1, 3)
-    if y.shape[-1] == 1:
+    if kind == "value":
         _, g = hip_ops.query(model.hip_cfg, model.flat_parameters(), x2, want_grad=True)
         jac = g.reshape(1, -1, 1, 3)
-    elif getattr(y, "_dudf_kind", None) == "eig_normal":
+    elif kind == "eig_normal":
         _, _, _, _, shape = hip_ops.query_curvature(model.hip_cfg, model.flat_parameters(), x2, want_shape=True)
         jac = shape.reshape(1, -1, 3, 3)
     else:

@@ -185,8 +185,13 @@ def test_divergence_laplace_and_derived_outputs(golden_dir):
         h1 = dif.hessian(y.squeeze(-1), xin)
         h2 = dif.hessian(y, xin)
         assert torch.equal(h1, h2)
-        g1 = dif.gradient(y.reshape(1, -1, 1) * 1.0, xin)
+        g1 = dif.gradient(y.reshape(1, -1, 1).clone(), xin)
         assert torch.equal(g1, g)
+        for bad in (y * 1.0, 2 * y, y.abs(), torch.tanh(y.squeeze(-1))):   # FUNCTIONS of the output have no HIP path: loud
+            with pytest.raises(Exception):
+                dif.gradient(bad, xin)
+            with pytest.raises(Exception):
+                dif.hessian(bad, xin)
         normals, _ = compute_normals_and_cd(xin, y)
         dn = dif.divergence(normals, xin)[0, :, 0].cpu().numpy().astype(np.float64)
         sgn = np.sign((normals[0].cpu().numpy() * G6[f"{tag}_f64_n"]).sum(1))

@@ -1,0 +1,95 @@
+# coding: utf-8
+"""GPU: oracle-direct parity at BASELINE.json's full sizes — the step `bench.py` times, against the fp64 oracle.
+
+    SIREN 8x256 at 100 000 points (the headline metric) and 8x512 at 125 000 points (config 3's per-GPU share):
+      * the four `loss_s1` terms and the FULL d(theta) against `oracle.dudf_oracle.loss_and_grad` in fp64 (torch CPU
+        backend, the one `bench.py::cpu_baseline` runs), evaluated in point chunks: every term of `loss_s1` is a mean
+        over points, so the batch result is the n_chunk/N-weighted sum of the chunk results;
+      * every stashed per-point intermediate (s, c, q of the forward / reverse sweeps; A, e, zbar of the adjoint sweeps)
+        of one random column out of EVERY 128-column pass of every workgroup, all layers.
+    Tolerances are the ones of tests/test_hip_parity.py (reference: src/loss_functions.py:123-155, src/model.py:94-108).
+"""
+import numpy as np
+import pytest
+import torch
+
+from diffudf_amd import synth
+from oracle import dudf_oracle as O
+
+pytestmark = pytest.mark.gpu
+W = [1e4, 1e4, 0.0, 1e3]
+TOL_TERM, TOL_DTHETA = 1e-5, 1e-4
+CHUNK = 12500
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def oracle_full(P64, x, nrm, sdf, n):
+    """loss terms (4,) and flat d(theta) of the whole batch, fp64, chunked over points."""
+    Pt = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in P64]
+    terms = np.zeros(4)
+    grad = None
+    with torch.no_grad():
+        for lo in range(0, n, CHUNK):
+            hi = min(n, lo + CHUNK)
+            xs, ns, ss = [torch.from_numpy(a[lo:hi].astype(np.float64)) for a in (x, nrm, sdf)]
+            t, g, _ = O.loss_and_grad("s1", Pt, xs, ns, ss, W, 100.0, xp=torch)
+            f = (hi - lo) / n
+            terms += f * np.array([float(v) for v in t.values()])
+            flat = torch.cat([torch.cat([w.reshape(-1), b.reshape(-1)]) for w, b in g]).numpy() * f
+            grad = flat if grad is None else grad + flat
+    return terms, grad
+
+
+@pytest.mark.parametrize("hidden,n", [([256] * 8, 100000), ([512] * 8, 125000)])
+def test_step_against_oracle_at_full_size(hidden, n):
+    from diffudf_amd import hip_ops as hip
+    P32 = synth.siren_params(hidden, seed=123)
+    P64 = [(w.astype(np.float64), b.astype(np.float64)) for w, b in P32]
+    x, nrm, sdf = synth.training_batch(n, seed=124)
+    th = torch.from_numpy(synth.flatten_params(P32)).cuda()
+    xd, nd, sd = [torch.from_numpy(a).cuda() for a in (x, nrm, sdf.reshape(-1))]
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda")
+    terms = hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W, 100.0, ws).double().cpu().numpy()
+    dth = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W, 100.0, torch.ones(4, device="cuda"), None, ws)
+    dth = dth.double().cpu().numpy()
+
+    # one random column of every 128-column pass (a pass = the 8 waves x 16 columns a workgroup walks together)
+    rng = np.random.default_rng(5)
+    starts = np.arange(0, n, 128)
+    idx = np.minimum(starts + rng.integers(0, 128, starts.size), n - 1)
+    L = len(hidden)
+    got = {}
+    for name in ("s", "c", "q", "A", "e", "zbar"):
+        for l in range(L):
+            got[name, l] = hip.read_stash(cfg, name, l, n, ws)[torch.from_numpy(idx).cuda()].double().cpu().numpy()
+    sub = [a[idx].astype(np.float64) for a in (x, nrm, sdf)]
+    _, _, dbg = O.loss_and_grad("s1", P64, *sub, W, 100.0)
+    f = idx.size / n                                     # the oracle's cotangents carry 1 / (its own batch size)
+    worst = {}
+    for l in range(L):
+        for name, ref, scale, tol in (("s", dbg["cache"]["s"][l], 1.0, 5e-5), ("c", dbg["cache"]["c"][l], 1.0, 5e-5),
+                                      ("q", dbg["rev"]["q"][l], 1.0, 5e-5), ("A", dbg["trace"]["A"][l], f, 2e-4),
+                                      ("e", dbg["trace"]["e"][l], f, 2e-4), ("zbar", dbg["trace"]["zbar"][l], f, 2e-4)):
+            e = rel(got[name, l], ref * scale)
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < tol, f"{hidden[0]}x{L} n={n}: stash {name}[{l}] rel err {e:.2e} on {idx.size} columns"
+
+    t_ref, g_ref = oracle_full(P64, x, nrm, sdf, n)
+    et, ed = rel(terms, t_ref), rel(dth, g_ref)
+    # per parameter tensor too: a wrong thin layer or bias must not hide under the max-norm of the hidden matrices
+    H = hidden[0]
+    offs, o = [], 0
+    for w_, b_ in P32:
+        offs.append((o, o + w_.size)); o += w_.size
+        offs.append((o, o + b_.size)); o += b_.size
+    per = max(rel(dth[a:b], g_ref[a:b]) for a, b in offs)
+    print(f"full size {H}x{L} n={n}: terms {et:.2e} dtheta {ed:.2e} (worst single tensor {per:.2e}); stash "
+          + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    assert et < TOL_TERM
+    assert ed < TOL_DTHETA
+    assert per < 5 * TOL_DTHETA

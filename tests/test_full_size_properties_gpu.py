@@ -1,5 +1,6 @@
 # coding: utf-8
-"""GPU: size-independent properties at BASELINE.json's full sizes, where the CPU oracle cannot run the whole batch.
+"""GPU: size-independent properties at BASELINE.json's full sizes (the oracle-direct comparison of the same step at the
+same sizes is tests/test_full_size_oracle_gpu.py).
 
   * per-point independence: values / gradients of a 100 000-point query equal the oracle's on a random subset;
   * shard additivity (the multi-GPU invariant): loss terms and d(theta) of the full batch equal the sums over uneven
