@@ -37,6 +37,11 @@ bool dudf_deterministic() {
     return on;
 }
 
+bool dudf_split_fp16() {
+    static const bool on = [] { const char* e = getenv("DUDF_SPLIT"); return !(e && e[0] == 'b'); }();
+    return on;
+}
+
 namespace {
 
 // DUDF_SWEEP=f32 keeps every sweep on the f32-input MFMA kernel (A/B testing); default: bf16x6 where it is built
@@ -56,6 +61,11 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.theta = theta; a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt;
     a.wimg_f = reinterpret_cast<const char*>(ws + lo.ws_wimg);
     a.wimg_t = a.wimg_f + (size_t)(lo.L - 1) * lo.H * lo.H * 6;
+    a.wimg16_f = reinterpret_cast<const char*>(ws + lo.ws_wimg16);
+    a.wimg16_t = a.wimg16_f + (size_t)(lo.L - 1) * lo.H * lo.H * 4;
+    a.wsc = ws + lo.ws_wsc;
+    a.amax = reinterpret_cast<unsigned*>(ws + lo.ws_amax);
+    a.split = dudf_split_fp16() ? 1 : 0;
     a.x4 = ws + lo.ws_x4; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
     a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.ZS = ws + lo.ws_ZS; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R;
     a.E = ws + lo.ws_E; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z;

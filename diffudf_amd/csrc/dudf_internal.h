@@ -30,6 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   w1t16  [16][H]     rows 0..2 = W_1^T, rest 0: A-operand of the last reverse step (df/dx)
 //   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps (f32 kernel)
 //   wimg   bf16x3 images of W_l, then of W_l^T, in A-fragment order (dudf_sweep_bf16.hip)
+//   wimg16 fp16 hi/lo images of 2^k_l W_l, then of 2^k_l W_l^T (same order, two pieces; "fp16x3" split)
+//   wsc    [2][L-1]: 2^-k_l (what the accumulators of matrix l are multiplied with), then 2^k_l
+//   amax   [4][L] uint: bit patterns of max |q_l|, |A_l|, |zbar_l| over all columns of the step (fp16x3 weight-gradient GEMM)
 //   per column: x4 [np][4] = layer-1 B operand (x,1 | e_k,0), y [np], g [np][4] (a_0 rows), ybar [np], gbar [np][4]
 //   stash arrays, each [L][H/4][np][4]:  element (layer li, feature f, column p) lives at
 //       ((li*(H/4) + f/4)*np + p)*4 + f%4
@@ -51,7 +54,7 @@ struct DudfLayout {
     // theta
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
-    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
+    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
     int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array
     size_t total_bytes;
@@ -84,6 +87,9 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_w1t16 = take(16 * (int64_t)H);
     lo->ws_wt = take((int64_t)(L - 1) * H * H);
     lo->ws_wimg = take((int64_t)(L - 1) * H * H * 3);      // bf16x3 images of W_l and W_l^T: 2 x 6 bytes per weight
+    lo->ws_wimg16 = take((int64_t)(L - 1) * H * H * 2);    // fp16 hi/lo images of W_l and W_l^T: 2 x 4 bytes per weight
+    lo->ws_wsc = take(2 * (int64_t)(L > 1 ? L - 1 : 1));
+    lo->ws_amax = take(4 * (int64_t)L);
     lo->ws_x4 = take(4 * lo->np);
     lo->ws_y = take(lo->np); lo->ws_g = take(4 * lo->np);
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
@@ -115,6 +121,10 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
 struct SweepArgs {
     const float* theta; const float* w1b; const float* w1t16; const float* wt;
     const char* wimg_f; const char* wimg_t;   // bf16x3 weight images (forward / transposed), dudf_sweep_bf16.hip
+    const char* wimg16_f; const char* wimg16_t;   // fp16 hi/lo weight images, scaled by 2^k_l per matrix
+    const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l
+    unsigned* amax;           // [4][L]: running maxima of |q_l|, |A_l|, |zbar_l| (bit patterns), or nullptr
+    int split;                // 0: bf16x6 everywhere; 1: fp16x3 where it is built (DUDF_SPLIT)
     const float* x4;          // [np][4]: layer-1 B operand per column
     float* y; float* g;       // [np], [np][4]
     const float* ybar; const float* gbar;
@@ -177,6 +187,9 @@ int dudf_launch_curvature(const float* yj, const float* lam, const float* V, int
 // one block for the thin layers), so repeated launches give bit-identical results.  A test mode: the weight-gradient
 // GEMM then runs on 7 CUs.
 bool dudf_deterministic();
+// DUDF_SPLIT=bf16 keeps every hidden matmul on the exact three-piece bf16 split (six products); default: the fp16 hi/lo
+// split (three products) where it is built.  Read once.
+bool dudf_split_fp16();
 
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,

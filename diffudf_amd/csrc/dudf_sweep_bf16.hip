@@ -37,20 +37,29 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NWB = 8;                                 // waves per workgroup: two per SIMD
 constexpr int TILEB = NWB * 16;                        // columns per workgroup pass
 
-template <int H>
+// SP = 0: exact three-piece bf16 split, six products ("bf16x6").  SP = 1: fp16 hi/lo split, three products ("fp16x3"):
+// v * 2^k = hi + lo with two round-to-nearest fp16 pieces (|v 2^k - hi - lo| <= 2^-23 |v 2^k|; fp16 subnormals are
+// produced by v_cvt_pk_f16_f32 and honoured by the MFMA — tools/micro/f16_split.hip, profiles/r03_f16_split_facts.txt),
+// products hi*hi + hi*lo + lo*hi; the dropped lo*lo is <= 2^-22 of the product.  Half the matrix-core work, a third less
+// LDS traffic, 2 conversions instead of 3 per value; the price is fp16's range: the weights are scaled per matrix by a power
+// of two (pack kernel), the activations where their size is not known a priori (see `ColScale`).
+template <int H, int SP = 0>
 struct GeoB {
+    static constexpr int NPC = SP ? 2 : 3;             // pieces per operand
     static constexpr int NT = H / 16;                  // 16-feature tiles per activation vector
     static constexpr int NKB = H / 32;                 // 32-feature k-blocks = weight chunks per layer
-    static constexpr int FRAG = 1024;                  // bytes of one A fragment: 64 lanes x 8 bf16
-    static constexpr int CHUNKB = NT * 3 * FRAG;       // one k-block of a matrix: [tile][piece]
-    static constexpr int IMGB = NKB * CHUNKB;          // one matrix: 6 bytes per weight
-    static constexpr int NDMA = NT * 3 / NWB;          // LDS-DMA wave-instructions per wave and chunk
+    static constexpr int FRAG = 1024;                  // bytes of one A fragment: 64 lanes x 8 x 16 bits
+    static constexpr int CHUNKB = NT * NPC * FRAG;     // one k-block of a matrix: [tile][piece]
+    static constexpr int IMGB = NKB * CHUNKB;          // one matrix: 6 (4) bytes per weight
+    static constexpr int NDMA = NT * NPC / NWB;        // LDS-DMA wave-instructions per wave and chunk
     static constexpr int NTHR = 64 * NWB;
 };
 
@@ -79,6 +88,29 @@ __device__ __forceinline__ void split8(const f32x4 e0, const f32x4 e1, u32x4& h,
         h[i] = hp; m[i] = mp; l[i] = cvt_pk(r2);
     }
 }
+__device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) {
+#if DUDF_SWEEP_DBG & 4
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c;
+#endif
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// 8 fp32 values -> the two fp16x8 pieces hi = fp16(v), lo = fp16(v - hi) (the caller has scaled v into fp16's range)
+__device__ __forceinline__ void split8h(const f32x4 e0, const f32x4 e1, u32x4& h, u32x4& l) {
+    const f32x2 v[4] = {{e0[0], e0[1]}, {e0[2], e0[3]}, {e1[0], e1[1]}, {e1[2], e1[3]}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 hp = __builtin_convertvector(v[i], f16x2);      // v_cvt_pk_f16_f32, round to nearest even
+        // r = v - hi, exact.  v_fma_mix_f32 reads the fp16 half directly (no v_cvt_f32_f16) and issues beside the SIMD
+        // partner's MFMAs like a plain v_fma_f32 (tools/micro/coissue.hip); hipcc folds `fma(v, 1, -hi)` back into
+        // convert + subtract, hence the asm
+        f32x2 r;
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r.x) : "v"(v[i].x), "v"(hp));
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r.y) : "v"(v[i].y), "v"(hp));
+        h[i] = __builtin_bit_cast(unsigned, hp);
+        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    }
+}
+__device__ __forceinline__ f16x8 as_h(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ u32x4 as_u(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
 __device__ __forceinline__ f32x4 as_f(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
@@ -87,10 +119,10 @@ __device__ __forceinline__ f32x4 as_f(u32x4 v) { return __builtin_bit_cast(f32x4
 // `lds_off` is the buffer's LDS byte offset, `voff` = lane * 16; this wave moves pieces wave*NDMA .. +NDMA-1.  One asm
 // block: scalar base + lane offset addressing, M0 (the LDS destination) saved and restored once — under 2 instructions
 // per piece instead of 11 through generic pointers.
-template <int H>
+template <int H, int SP = 0>
 __device__ __forceinline__ void dma_issue(const char* __restrict__ chunk, unsigned lds_off, unsigned voff, int wave) {
-    using G = GeoB<H>;
-    static_assert(G::NDMA == 6 || G::NDMA == 3, "asm below is written for 3 or 6 pieces per wave");
+    using G = GeoB<H, SP>;
+    static_assert(G::NDMA == 6 || G::NDMA == 3 || G::NDMA == 4 || G::NDMA == 2, "asm below is written for 2, 3, 4 or 6 pieces per wave");
 #if DUDF_SWEEP_DBG & 8
     return;
 #endif
@@ -112,11 +144,25 @@ __device__ __forceinline__ void dma_issue(const char* __restrict__ chunk, unsign
                      "global_load_lds_dwordx4 %4, %2 offset:1024\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l0), "v"(voff + 4096u) : "memory", "scc");
-    } else {
+    } else if constexpr (G::NDMA == 4) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\t"
                      "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                      "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l0) : "memory");
+    } else if constexpr (G::NDMA == 3) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l0) : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l0) : "memory");
     }
@@ -141,10 +187,12 @@ struct TailOps { f32x4 o1a, o2a, o3a, o1b, o2b, o3b, ba, bb; };   // operands of
 
 // One pass: the workgroup's waves 0..nact-1 take the 16-column groups g_first.. through a whole sweep.  Waves beyond
 // nact (the last, partial pass of a workgroup's share) only keep the weight stream and the barriers going.
-template <int H, int SW, int FL>
+template <int H, int SW, int FL, int SP = 0>
 __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc,
                                              const bool stamp_on = false) {
-    using G = GeoB<H>;
+    using G = GeoB<H, SP>;
+    constexpr int NPC = G::NPC;
+    static_assert(SP == 0 || SW == SWEEP_FWD, "fp16x3: built for the forward sweep (|h_l| <= 1 needs no activation scale)");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -158,8 +206,13 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     f32x4 acc[G::NT], prev[G::NT];                     // this layer's accumulators / the previous layer's, tails pending
     const int64_t p = (int64_t)(g_first + wave) * 16 + li;
     auto image = [&](int j) -> const char* {
+        if constexpr (SP) return kFwdDir ? a.wimg16_f + (size_t)j * G::IMGB : a.wimg16_t + (size_t)(nhid - 1 - j) * G::IMGB;
         return kFwdDir ? a.wimg_f + (size_t)j * G::IMGB : a.wimg_t + (size_t)(nhid - 1 - j) * G::IMGB;
     };
+    // fp16x3: the accumulators of matrix j hold 2^k_j (W h); `unscale` = 2^-k_j of the matrix whose outputs wait in `prev`
+    // (1 for the first layer, which runs on the fp32 MFMA) — folded into the bias add of the forward tail
+    float unscale = 1.f;
+    auto unscale_of = [&](int j) -> float { return a.wsc[kFwdDir ? j : nhid - 1 - j]; };
     // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {   // forward sweep: b_{layer+1}
@@ -174,7 +227,14 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     auto load_ops = [&](int layer, int kb, TailOps& o) {
         epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vo, o.o1a, o.o2a, o.o3a);
         epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vo, o.o1b, o.o2b, o.o3b);
-        if constexpr (BS == SWEEP_FWD) {
+        if constexpr (BS == SWEEP_FWD && SP != 0) {
+            // fp16x3: every layer's bias sits in LDS behind the weight buffers (sweep_body_b) — a vector-memory instruction
+            // costs its wave ~100 cycles of issue when the CU's eight waves contend (s_memtime timeline: the two bias loads
+            // held the waves that multiply first for 600 cycles of every step), an LDS read 4
+            const float* lb = reinterpret_cast<const float*>(lds + 3 * G::CHUNKB) + layer * H + 32 * kb + 4 * q;
+            o.ba = *reinterpret_cast<const f32x4*>(lb);
+            o.bb = *reinterpret_cast<const f32x4*>(lb + 16);
+        } else if constexpr (BS == SWEEP_FWD) {
             o.ba = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 32 * kb + 4 * q);
             o.bb = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 32 * kb + 16 + 4 * q);
         }
@@ -182,7 +242,10 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // tail of tiles 2kb, 2kb+1 of `layer`: fp32 results (and the stash stores the sweep owes)
     auto run_tail = [&](int layer, int kb, const f32x4 z0, const f32x4 z1, const TailOps& o, f32x4& e0, f32x4& e1) {
         const f32x4 zero = {0, 0, 0, 0};
-        if constexpr (BS == SWEEP_FWD) {             // z = W h + b only in the value channel
+        if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
+            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv);
+            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv);
+        } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
             e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv);
             e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv);
         } else {
@@ -212,7 +275,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // waves that multiply first (4-7, see `late` below) are the ones the step waits for — their chain loses the six pieces,
     // the other half, which idled at the barrier, takes them (-0.9 % on the step; the reverse assignment: no gain).
     auto dma2 = [&](const char* src, unsigned dst) {
-        if (wave < NWB / 2) { dma_issue<H>(src, dst, voff, wave); dma_issue<H>(src, dst, voff, wave + NWB / 2); }
+        if (wave < NWB / 2) { dma_issue<H, SP>(src, dst, voff, wave); dma_issue<H, SP>(src, dst, voff, wave + NWB / 2); }
     };
     dma2(chunk_src(0), lds0 + gc * G::CHUNKB);
     dma2(chunk_src(1), lds0 + ((gc + 1) % 3) * G::CHUNKB);
@@ -253,21 +316,25 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // loaded right behind the DMA: a full step ahead); the quad variants have a third operand array and no registers
     // for that — one set, refilled right after the tail that consumed it (about 0.8 step ahead).
     TailOps ops_cur, ops_n1;
-    u32x4 bh, bm, bl;                                  // B operand of the current step
+    u32x4 bp[NPC];                                     // B operand of the current step: bf16 h | m | l, or fp16 hi | lo
+    auto split = [&](const f32x4 e0, const f32x4 e1, u32x4 (&o)[NPC]) {
+        if constexpr (SP) split8h(e0, e1, o[0], o[1]);
+        else split8(e0, e1, o[0], o[1], o[2]);
+    };
     f32x4 fin0 = {0, 0, 0, 0}, fin1 = {0, 0, 0, 0};    // fp32 results of pair 0 of the layer after the last matrix
     load_ops(in_layer(0), 0, ops_cur);
     if constexpr (!HS) load_ops(in_layer(0), 1, ops_n1);
     {
         f32x4 e0, e1;
         run_tail(in_layer(0), 0, prev[0], prev[1], ops_cur, e0, e1);
-        split8(e0, e1, bh, bm, bl);
+        split(e0, e1, bp);
         if constexpr (HS) load_ops(in_layer(0), 1, ops_cur);
     }
 #pragma unroll
     for (int T = 0; T < G::NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
     dma_wait_b<0>();                                   // once per tile: chunks 0 and 1 and everything above
     __syncthreads();
-    constexpr int kYoung = younger_ops<SW, FL>();
+    constexpr int kYoung = younger_ops<SW, FL>() - ((SP != 0 && BS == SWEEP_FWD) ? 2 : 0);   // fp16x3 forward: the bias comes from LDS
     // The two waves of a SIMD (w, w + 4) leave every k-block barrier together.  With the same program order both run
     // their tail (vector ALU) at the same time and then collide on the matrix pipe: the step costs tail + MFMAs of both.
     // Waves 4-7 therefore run their MFMAs FIRST and the tail of the next step behind them (the tail only needs the
@@ -281,6 +348,15 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 #endif
     // feed slot: after which tile's MFMAs a wave issues its DMA pieces and operand loads (-1: at the top of the step);
     // tail slot: after which tile's MFMAs it runs the tail of the next step.  A = waves 0-3, B = waves 4-7 (when `late`).
+#ifndef DUDF_TP
+#define DUDF_TP (SP ? 2 : 1)
+#endif
+#ifndef DUDF_AD
+#define DUDF_AD 4
+#endif
+#ifndef DUDF_TAIL_TOP
+#define DUDF_TAIL_TOP (SP != 0)
+#endif
 #ifndef DUDF_FA
 #define DUDF_FA -1
 #define DUDF_TA 0
@@ -293,12 +369,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 #pragma unroll
         for (int kb = 0; kb < G::NKB; ++kb) {
             const int c = j * G::NKB + kb;
-            const char* bp = lds + gc * G::CHUNKB + lane * 16;
-            auto frag = [&](int T, int pc) -> bf16x8 {
+            const char* bpl = lds + gc * G::CHUNKB + lane * 16;
+            auto frag = [&](int T, int pc) -> u32x4 {
 #if DUDF_SWEEP_DBG & 32
-                bf16x8 z; asm volatile("" : "=v"(z)); return z;
+                u32x4 z; asm volatile("" : "=v"(z)); return z;
 #endif
-                return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
+                return *reinterpret_cast<const u32x4*>(bpl + (T * NPC + pc) * G::FRAG);
             };
             DUDF_STAMP(0);
             if constexpr (!HS) ops_cur = ops_n1;
@@ -312,41 +388,90 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 if (more) dma2(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB);
                 if constexpr (!HS) load_after_next(ops_n1);          // one full step ahead
             };
+            u32x4 nb[NPC];
+            // fp16x3: the half that does not multiply first runs its tail at the very top of the step, in front of its DMA
+            // pieces (fetched two steps ahead: no hurry) and of its first LDS fragment: the step is (tail of one half beside the
+            // MFMAs of the other) twice, and neither tail should wait for anything
+            constexpr bool kTailTop = DUDF_TAIL_TOP;
+            if (kTailTop && !late && kb + 1 < G::NKB) {
+                DUDF_STAMP(2);
+                f32x4 e0, e1;
+                run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
+                split(e0, e1, nb);
+                if constexpr (HS) load_after_next(ops_cur);
+                DUDF_STAMP(3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if ((FA < 0 && !late) || (FB < 0 && late)) feed();
             DUDF_STAMP(1);
             __builtin_amdgcn_sched_barrier(0);
-            u32x4 nh, nm, nl;
             // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
             // chunk DMA on the LDS, one tile of distance does not cover the read latency
-            bf16x8 an[2][3] = {{frag(0, 0), frag(0, 1), frag(0, 2)}, {frag(1, 0), frag(1, 1), frag(1, 2)}};
+            // (fp16x3: FOUR tiles = 12 MFMAs: a tile is only three MFMAs long)
+            constexpr int AD = SP ? DUDF_AD : 2;
+            u32x4 an[AD][NPC];
+#pragma unroll
+            for (int T = 0; T < AD; ++T)
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) an[T][pc] = frag(T, pc);
 #ifdef DUDF_MPRIO
             __builtin_amdgcn_s_setprio(1);                              // the wave that multiplies wins the issue arbitration
 #endif
+            // TP tiles per trip, their MFMA chains interleaved: a tile's products accumulate into ONE register quad, and a
+            // wave that issues them back to back waits out each MFMA's latency (fp16x3: three-instruction chains — alone on
+            // the pipe a wave reached one MFMA per ~34 cycles instead of 16)
+            constexpr int TP = DUDF_TP;
 #pragma unroll
-            for (int T = 0; T < G::NT; ++T) {
-                const bf16x8 ah = an[T & 1][0], am = an[T & 1][1], al = an[T & 1][2];
-                if (T + 2 < G::NT) {
-                    an[T & 1][0] = frag(T + 2, 0); an[T & 1][1] = frag(T + 2, 1); an[T & 1][2] = frag(T + 2, 2);
+            for (int T = 0; T < G::NT; T += TP) {
+                u32x4 af[TP][NPC];
+#pragma unroll
+                for (int u = 0; u < TP; ++u)
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) af[u][pc] = an[(T + u) % AD][pc];
+                if (T + AD < G::NT) {
+#pragma unroll
+                    for (int u = 0; u < TP; ++u)
+#pragma unroll
+                        for (int pc = 0; pc < NPC; ++pc) an[(T + u) % AD][pc] = frag(T + u + AD, pc);
                     // vector/scalar ALU and vector memory may move across, LDS reads and MFMAs may not: otherwise hipcc
                     // floats each tile's MFMAs up to its reads and every fragment is waited for just in time
                     __builtin_amdgcn_sched_barrier(0x76);
                 }
-                f32x4 cc = acc[T];
-                cc = mfma_b(am, as_bf(bm), cc);                         // smallest terms first
-                cc = mfma_b(al, as_bf(bh), cc);
-                cc = mfma_b(ah, as_bf(bl), cc);
-                cc = mfma_b(am, as_bf(bh), cc);
-                cc = mfma_b(ah, as_bf(bm), cc);
-                cc = mfma_b(ah, as_bf(bh), cc);
-                acc[T] = cc;
-                if ((T == FA && !late) || (T == FB && late)) {                       // the late half issues its DMA pieces (60-180 cycles
+                f32x4 cc[TP];
+#pragma unroll
+                for (int u = 0; u < TP; ++u) cc[u] = acc[T + u];
+                if constexpr (SP) {                                     // smallest terms first: lo*hi, hi*lo, hi*hi
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_h(as_h(af[u][1]), as_h(bp[0]), cc[u]);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_h(as_h(af[u][0]), as_h(bp[1]), cc[u]);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_h(as_h(af[u][0]), as_h(bp[0]), cc[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_b(as_bf(af[u][1]), as_bf(bp[1]), cc[u]);   // smallest terms first
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_b(as_bf(af[u][2]), as_bf(bp[0]), cc[u]);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_b(as_bf(af[u][0]), as_bf(bp[2]), cc[u]);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_b(as_bf(af[u][1]), as_bf(bp[0]), cc[u]);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_b(as_bf(af[u][0]), as_bf(bp[1]), cc[u]);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) cc[u] = mfma_b(as_bf(af[u][0]), as_bf(bp[0]), cc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < TP; ++u) acc[T + u] = cc[u];
+                const int Tl = T + TP - 1;                              // last tile of this trip
+                if ((FA >= T && FA <= Tl && !late) || (FB >= T && FB <= Tl && late)) {   // the late half issues its DMA pieces (60-180 cycles
                     __builtin_amdgcn_sched_barrier(0);                  // of issue each) under the other half's MFMAs
                     DUDF_STAMP(6);
                     feed();
                     DUDF_STAMP(7);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (kb + 1 < G::NKB && ((T == TA && !late) || (T == TB && late))) {   // the next step's B operand
+                if (kb + 1 < G::NKB && ((TA >= T && TA <= Tl && !late && !kTailTop) || (TB >= T && TB <= Tl && late))) {   // the next step's B operand
                     if (T != 0) __builtin_amdgcn_sched_barrier(0);
                     DUDF_STAMP(2);
 #ifdef DUDF_MPRIO
@@ -354,10 +479,10 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 #endif
                     f32x4 e0, e1;
                     run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
-                    split8(e0, e1, nh, nm, nl);
+                    split(e0, e1, nb);
                     if constexpr (HS) load_after_next(ops_cur);
 #ifdef DUDF_MPRIO
-                    if (T + 1 < G::NT) __builtin_amdgcn_s_setprio(1);
+                    if (Tl + 1 < G::NT) __builtin_amdgcn_s_setprio(1);
 #endif
                     DUDF_STAMP(3);
                 }
@@ -366,19 +491,22 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             __builtin_amdgcn_s_setprio(0);
 #endif
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
+                if constexpr (SP) unscale = unscale_of(j);
                 run_tail(lnx, 0, acc[0], acc[1], ops_cur, fin0, fin1);
-                split8(fin0, fin1, nh, nm, nl);
+                split(fin0, fin1, nb);
                 if constexpr (HS) load_after_next(ops_cur);
 #pragma unroll
                 for (int T = 0; T < G::NT; ++T) { prev[T] = acc[T]; acc[T] = f32x4{0, 0, 0, 0}; }
             }
-            bh = nh; bm = nm; bl = nl;
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) bp[pc] = nb[pc];
             gc = (gc + 1) % 3;
             DUDF_STAMP(4);
 #if !(DUDF_SWEEP_DBG & 8)
             // chunk c+1 landed; c+2 and two steps' stash traffic stay in flight.  Only the waves that issued DMA pieces wait
             // (0-3: the barrier behind publishes the chunk to the others)
-            if (more) { if (wave < NWB / 2) dma_wait_b<2 * kYoung + 2 * G::NDMA>(); }
+            // (tail at the top of the step: its stores are OLDER than this step's pieces — one step of stash traffic less)
+            if (more) { if (wave < NWB / 2) dma_wait_b<(kTailTop ? 1 : 2) * kYoung + 2 * G::NDMA>(); }
             else dma_wait_b<0>();
 #endif
             DUDF_STAMP(5);
@@ -429,10 +557,17 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     }
 }
 
-template <int H, int SW, int FL>
+template <int H, int SW, int FL, int SP = 0>
 __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
+    if constexpr (SP != 0 && base_of(SW) == SWEEP_FWD) {     // b_1 .. b_L behind the three weight buffers (read by the tails)
+        float* lb = reinterpret_cast<float*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
+        for (int i = threadIdx.x; i < a.L * H; i += 64 * NWB) {
+            const int layer = i / H, f = i - layer * H;
+            lb[i] = layer == 0 ? a.theta[3 * H + f] : a.theta[a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H + f];
+        }
+    }
     // the two waves of a SIMD (w, w + 4) leave every k-block barrier in lockstep: tails coincide, MFMA streams collide.
     // A static priority for one half lets it run its tail first at every contended issue slot; the partner falls one tail
     // behind and from then on overlaps its tail with the other's MFMAs (MI355X_MICROARCH.md, "two waves per SIMD", 4 and 9)
@@ -443,7 +578,7 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
-        sweep_tile_b<H, SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && blockIdx.x == 100 && g == g0);
+        sweep_tile_b<H, SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && blockIdx.x == 100 && g == g0);
 }
 // Two code generations of the same body.  The packed fp32 instructions (v_pk_fma_f32 ...) halve the vector-ALU issue
 // slots of a tail, but they do not execute beside the SIMD partner's MFMAs (tools/micro/coissue.hip: 48 v_pk_fma_f32 +
@@ -456,6 +591,11 @@ template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_bf16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
+// the fp16x3 builds (own names: tests/isa_contract.py tells the two families apart by them)
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a); }
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a); }
 
 // theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L
 template <int H>
@@ -490,11 +630,62 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
     }
 }
 
+// theta -> fp16 hi/lo images of 2^k_j W_l and 2^k_j W_l^T in the same A-fragment order, k_j = 15 - (exponent of max |W_l|):
+// the largest weight lands in [2^14, 2^15), weights down to 2^-18 of it keep two full pieces, smaller ones an absolute
+// error of 2^-40 of the largest.  grid = (blocks per matrix, L - 1); every block reduces max |W_l| itself (256 KB from L2).
+template <int H>
+__global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__ theta, char* __restrict__ img_f,
+                                                       char* __restrict__ img_t, float* __restrict__ wsc, int nhid,
+                                                       int64_t off_hid, int64_t hid_stride) {
+    using G = GeoB<H, 1>;
+    const int j = blockIdx.y;
+    const float* W = theta + off_hid + (int64_t)j * hid_stride;
+    __shared__ float red[4];
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < H * H / 4; i += 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(W)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int ex = 0;
+    (void)frexpf(mx, &ex);                              // mx < 2^ex (0 -> 0; inf / nan: whatever, the step is lost anyway)
+    ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+    const float sc = ldexpf(1.f, 15 - ex);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { wsc[j] = ldexpf(1.f, ex - 15); wsc[nhid + j] = sc; }
+    const int per = 2 * G::NKB * G::NT * 64;            // lane-items of this matrix: [dir][k-block][tile][lane]
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < per; idx += gridDim.x * 256) {
+        int v = idx;
+        const int lane = v & 63; v >>= 6;
+        const int T = v % G::NT; v /= G::NT;
+        const int kb = v % G::NKB; v /= G::NKB;
+        const int dir = v;
+        const int m = lane & 15, g = lane >> 4;
+        const int row = 16 * T + m;
+        f32x4 e0, e1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f0 = 32 * kb + 4 * g + e, f1 = f0 + 16;
+            e0[e] = sc * (dir == 0 ? W[(int64_t)row * H + f0] : W[(int64_t)f0 * H + row]);
+            e1[e] = sc * (dir == 0 ? W[(int64_t)row * H + f1] : W[(int64_t)f1 * H + row]);
+        }
+        u32x4 h, l;
+        split8h(e0, e1, h, l);
+        char* base = (dir == 0 ? img_f : img_t) + (size_t)j * G::IMGB + (size_t)kb * G::CHUNKB + (size_t)T * 2 * G::FRAG + lane * 16;
+        *reinterpret_cast<u32x4*>(base) = h;
+        *reinterpret_cast<u32x4*>(base + G::FRAG) = l;
+    }
+}
+
 template <int H, int SW, int FL>
 const void* sweep_kernel_ptr() {
     if constexpr (sweep_no_pk<SW>()) return reinterpret_cast<const void*>(&sweep_bf16_np_kernel<H, SW, FL>);
     else return reinterpret_cast<const void*>(&sweep_bf16_kernel<H, SW, FL>);
 }
+constexpr int kMaxLdsBiasLayers = 32;                  // fp16x3 forward sweep: b_1..b_L live in LDS (32 KiB at H = 256); deeper nets: bf16x6
 template <int H>
 int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoB<H>;
@@ -517,6 +708,27 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         else                                                                                                \
             hipLaunchKernelGGL((sweep_bf16_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);     \
     } while (0)
+#define DUDF_GO_H(SW, FL)                                                                                   \
+    do {                                                                                                    \
+        static bool attr_done = false;                                                                      \
+        const size_t smem_h = 3 * GeoB<H, 1>::CHUNKB + (size_t)a.L * H * sizeof(float);   /* + the biases */   \
+        if (!attr_done) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_f16_np_kernel<H, SW, FL>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,                             \
+                                    (int)(3 * GeoB<H, 1>::CHUNKB + kMaxLdsBiasLayers * H * sizeof(float))); \
+            if (e != hipSuccess) return (int)e;                                                             \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((sweep_f16_np_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem_h, st, a);     \
+    } while (0)
+    if (a.split == 1 && which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {   // fp16x3 (DUDF_SPLIT): the forward sweep of the plain columns
+        if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3);
+        else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2);
+        else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0);
+        else return DUDF_E_BADMODE;
+        return (int)hipGetLastError();
+    }
+#undef DUDF_GO_H
     switch (which) {
         case SWEEP_FWD:
             if (a.store_s && a.store_c) DUDF_GO_B(SWEEP_FWD, 3);
@@ -866,6 +1078,13 @@ int pack_b(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) 
     const int64_t total = (int64_t)2 * (lo.L - 1) * G::NKB * G::NT * 64;
     hipLaunchKernelGGL(pack_bf16_kernel<H>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, theta, img_f, img_t,
                        lo.L - 1, lo.off_hid, lo.hid_stride);
+    if (dudf_split_fp16()) {
+        using G1 = GeoB<H, 1>;
+        char* i16_f = reinterpret_cast<char*>(ws + lo.ws_wimg16);
+        char* i16_t = i16_f + (size_t)(lo.L - 1) * G1::IMGB;
+        hipLaunchKernelGGL(pack_f16_kernel<H>, dim3(H >= 256 ? 16 : 4, lo.L - 1), dim3(256), 0, st, theta, i16_f, i16_t,
+                           ws + lo.ws_wsc, lo.L - 1, lo.off_hid, lo.hid_stride);
+    }
     return (int)hipGetLastError();
 }
 }  // namespace

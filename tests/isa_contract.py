@@ -158,3 +158,49 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
     bad2, _ = replay(fifo)
     scratch = sum(1 for _, b in blocks for x in b if x.startswith("scratch_"))
     return {"bad": bad1 + bad2, "loads": loads, "carried": carried, "scratch": scratch}
+
+
+def analyse_f16(asm_path, width=256):
+    """fp16x3 sweep kernels (sweep_f16*_kernel in dudf_sweep_bf16.hip).  The order of a step's vector-memory operations
+    differs between the two halves of a workgroup and from the bf16x6 kernels (the tail — and its stash stores — may run in
+    front of the step's DMA pieces), so the check replays the FIFO instead of comparing against a formula: vmcnt retires in
+    issue order, hence at every hand-written `s_waitcnt vmcnt(N)` exactly the N youngest operations may still be in
+    flight.  The chunk a step reads after its wait was issued BEFORE the previous hand-written wait: none of those DMA
+    pieces may be among the N youngest ("late" pieces).  Returns per kernel {"waits": [(N, late, slack)], "scratch"} where
+    slack = how many more operations the wait could have left in flight (0 = as loose as safety allows)."""
+    txt = open(asm_path).read()
+    out = {}
+    for m in re.finditer(r"^(_ZN\w*sweep_f16_(?:np_)?kernelILi%dELi(\d)ELi(\d)E\w*):[^\n]*$" % width, txt, re.M):
+        body = txt[m.end():txt.index("s_endpgm", m.end())]
+        in_asm, scratch, fifo, waits, epoch = False, 0, [], [], 0
+        for ln in body.split("\n"):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            if t.startswith("scratch_"):
+                scratch += 1
+            if t.startswith("global_load_lds"):
+                fifo.append(("dma", epoch))
+            elif re.match(r"(global_load|global_store|global_atomic|buffer_|flat_)", t):
+                fifo.append(("op", epoch))
+            elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                if not in_asm:                       # a compiler wait: retires, never harms
+                    fifo = fifo[len(fifo) - n:] if n < len(fifo) else fifo
+                    continue
+                young = fifo[len(fifo) - n:] if n else []
+                late = sum(1 for kind, ep in young if kind == "dma" and ep < epoch)
+                # slack: operations older than the N youngest that are NOT old DMA pieces, counted up to the first such piece
+                slack = 0
+                for kind, ep in reversed(fifo[:len(fifo) - n] if n else fifo):
+                    if kind == "dma" and ep < epoch:
+                        break
+                    slack += 1
+                if n:
+                    waits.append((n, late, slack))
+                fifo = young
+                epoch += 1
+        out[(int(m.group(2)), int(m.group(3)))] = {"waits": waits, "scratch": scratch}
+    return out

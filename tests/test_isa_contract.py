@@ -8,9 +8,24 @@ import pytest
 
 import sys, os as _os
 sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-from isa_contract import analyse, analyse_bf16, analyse_wgrad_presplit, emit_asm
+from isa_contract import analyse, analyse_bf16, analyse_f16, analyse_wgrad_presplit, emit_asm
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF16_SRC = os.path.join(REPO, "diffudf_amd", "csrc", "dudf_sweep_bf16.hip")
+
+
+@pytest.fixture(scope="module")
+def bf16_asm(tmp_path_factory):
+    """Assembly of dudf_sweep_bf16.hip per flag set, emitted once per test session (three builds, in parallel)."""
+    from concurrent.futures import ThreadPoolExecutor
+    d = tmp_path_factory.mktemp("sweep_bf16_asm")
+    builds = {"late0": ("-DDUDF_LATE_FORCE=0",), "late1": ("-DDUDF_LATE_FORCE=1",), "ship": ()}
+    paths = {k: str(d / f"{k}.s") for k in builds}
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("needs hipcc")
+    with ThreadPoolExecutor(3) as ex:
+        list(ex.map(lambda k: emit_asm(BF16_SRC, paths[k], flags=builds[k]), builds))
+    return paths
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
@@ -29,7 +44,7 @@ def test_dma_wait_counts(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-def test_bf16_sweep_wait_counts(tmp_path):
+def test_bf16_sweep_wait_counts(tmp_path, bf16_asm):
     """dudf_sweep_bf16.hip: every step's counted wait leaves exactly this step's DMA pieces and two steps of stash
     traffic in flight (a larger N would let a wave read a weight chunk that has not landed; a smaller one only
     stalls), the idle-wave loop waits for all but its newest pieces, and nothing spills at 2 waves per SIMD."""
@@ -40,8 +55,7 @@ def test_bf16_sweep_wait_counts(tmp_path):
     # operand loads at the top of a step, tail early; waves 4-7: MFMAs first, then DMA pieces, loads and tail).  The
     # count is a property of each order: check each one in a build where that order is the only one (straight-line steps).
     for force in (0, 1):
-        asm = str(tmp_path / f"sweep_bf16_{force}.s")
-        emit_asm(src, asm, flags=(f"-DDUDF_LATE_FORCE={force}",))
+        asm = bf16_asm[f"late{force}"]
         res = analyse_bf16(asm, ndma=12)
         assert set(res) == keys
         for key, v in res.items():
@@ -60,8 +74,7 @@ def test_bf16_sweep_wait_counts(tmp_path):
             assert any(s == (12, 0, 12) or s[2] == 12 for s in v["steps"]) or v["idle"], key   # the idle-wave loop's vmcnt(2 NDMA)
     # the shipped build: same kernels, nothing spills at 2 waves per SIMD, and the forward sweeps are the builds
     # without packed fp32 instructions (they do not execute beside the SIMD partner's MFMAs)
-    asm = str(tmp_path / "sweep_bf16.s")
-    emit_asm(src, asm)
+    asm = bf16_asm["ship"]
     res = analyse_bf16(asm, ndma=12)
     assert set(res) == keys
     assert all(v["scratch"] == 0 for v in res.values())
@@ -71,6 +84,32 @@ def test_bf16_sweep_wait_counts(tmp_path):
         body = txt[m.end():txt.index("s_endpgm", m.end())]
         assert "v_pk_fma_f32" not in body and "v_pk_mul_f32" not in body and "v_pk_add_f32" not in body
     assert len(re.findall(r"^_ZN\w*sweep_bf16_np_kernelILi256ELi0ELi\dE\w*:", txt, re.M)) == 3
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
+    """fp16x3 sweep kernels: replay of the vector-memory FIFO (tests/isa_contract.py::analyse_f16) for each half's program
+    order — no hand-written wait may leave a DMA piece of the chunk the next step reads in flight, the steady-state waits
+    are as loose as that allows, nothing spills, and the kernels are the builds without packed fp32 instructions."""
+    import re
+    src = os.path.join(REPO, "diffudf_amd", "csrc", "dudf_sweep_bf16.hip")
+    for force in (0, 1):
+        asm = bf16_asm[f"late{force}"]
+        res = analyse_f16(asm)
+        assert (0, 3) in res and (0, 2) in res and (0, 0) in res, sorted(res)
+        for key, v in res.items():
+            assert v["scratch"] == 0, (force, key)
+            assert len(v["waits"]) >= 8, (force, key, v["waits"])
+            for n, late, slack in v["waits"]:
+                assert late == 0, f"late={force} sweep_f16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) leaves {late} pieces of the next chunk in flight"
+            assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
+    txt = open(bf16_asm["ship"]).read()
+    names = re.findall(r"^(_ZN\w*sweep_f16_np_kernelILi256ELi\dELi\dE\w*):", txt, re.M)
+    assert len(names) >= 3
+    for m in re.finditer(r"^_ZN\w*sweep_f16_np_kernelILi256ELi\dELi\dE\w*:", txt, re.M):
+        body = txt[m.end():txt.index("s_endpgm", m.end())]
+        assert "v_pk_fma_f32" not in body and "v_pk_mul_f32" not in body and "v_pk_add_f32" not in body
+        assert body.count("v_fma_mix_f32") >= 64            # the residual of the fp16 split reads the fp16 half directly
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")

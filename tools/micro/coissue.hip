@@ -67,6 +67,14 @@ __global__ __launch_bounds__(512) void k(float* out, int mode, int iters, int nv
            "v_and_b32 %4, %4, %5\n\tv_and_b32 %5, %5, %6\n\tv_and_b32 %6, %6, %7\n\tv_and_b32 %7, %7, %0\n\t"
 #define D8 "v_dot2_f32_bf16 %0, %1, %2, %0\n\tv_dot2_f32_bf16 %1, %2, %3, %1\n\tv_dot2_f32_bf16 %2, %3, %4, %2\n\tv_dot2_f32_bf16 %3, %4, %5, %3\n\t" \
            "v_dot2_f32_bf16 %4, %5, %6, %4\n\tv_dot2_f32_bf16 %5, %6, %7, %5\n\tv_dot2_f32_bf16 %6, %7, %0, %6\n\tv_dot2_f32_bf16 %7, %0, %1, %7\n\t"
+#define M8 "v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %1, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %2, %2, %3, %4 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %3, %3, %4, %5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
+           "v_fma_mix_f32 %4, %4, %5, %6 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %5, %5, %6, %7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %6, %6, %7, %0 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %7, %7, %0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+#define C8 "v_cvt_pk_f16_f32 %0, %0, %1\n\tv_cvt_pk_f16_f32 %1, %1, %2\n\tv_cvt_pk_f16_f32 %2, %2, %3\n\tv_cvt_pk_f16_f32 %3, %3, %4\n\t" \
+           "v_cvt_pk_f16_f32 %4, %4, %5\n\tv_cvt_pk_f16_f32 %5, %5, %6\n\tv_cvt_pk_f16_f32 %6, %6, %7\n\tv_cvt_pk_f16_f32 %7, %7, %0\n\t"
+#define B8 "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %1, %1, %2\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %3, %3, %4\n\t" \
+           "v_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %5, %5, %6\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\tv_cvt_pk_bf16_f32 %7, %7, %0\n\t"
+#define H8 "v_cvt_f32_f16 %0, %1\n\tv_cvt_f32_f16 %1, %2\n\tv_cvt_f32_f16 %2, %3\n\tv_cvt_f32_f16 %3, %4\n\t" \
+           "v_cvt_f32_f16 %4, %5\n\tv_cvt_f32_f16 %5, %6\n\tv_cvt_f32_f16 %6, %7\n\tv_cvt_f32_f16 %7, %0\n\t"
         typedef float f2 __attribute__((ext_vector_type(2)));
         f2 y0 = {x0, x1}, y1 = {x1, x2}, y2 = {x2, x3}, y3 = {x3, x4}, y4 = {x4, x5}, y5 = {x5, x6}, y6 = {x6, x7}, y7 = {x7, x0};
         for (int it = 0; it < iters; ++it) {
@@ -74,6 +82,10 @@ __global__ __launch_bounds__(512) void k(float* out, int mode, int iters, int nv
                 if (kind == 0) asm volatile(F8 F8 F8 F8 F8 F8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
                 else if (kind == 1) asm volatile(P8 P8 P8 P8 P8 P8 : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));
                 else if (kind == 3) asm volatile(D8 D8 D8 D8 D8 D8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+                else if (kind == 4) asm volatile(M8 M8 M8 M8 M8 M8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+                else if (kind == 5) asm volatile(C8 C8 C8 C8 C8 C8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+                else if (kind == 6) asm volatile(B8 B8 B8 B8 B8 B8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+                else if (kind == 7) asm volatile(H8 H8 H8 H8 H8 H8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
                 else if (kind == 2) asm volatile(A8 A8 A8 A8 A8 A8 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
             }
         }
@@ -96,8 +108,8 @@ int main() {
     float* d; hipMalloc(&d, 256 * 512 * 4);
     const int iters = 20000;
     // per iteration: 24 (16x16x32) or 12 (32x32x16) MFMAs = 384 matrix-pipe cycles; VALU: 4 * nvalu instructions
-    const char* kn[4] = {"v_fma_f32", "v_pk_fma_f32", "v_and_b32", "v_dot2_f32_bf16"};
-    for (int kind = 0; kind < 4; ++kind)
+    const char* kn[8] = {"v_fma_f32", "v_pk_fma_f32", "v_and_b32", "v_dot2_f32_bf16", "v_fma_mix_f32", "v_cvt_pk_f16_f32", "v_cvt_pk_bf16_f32", "v_cvt_f32_f16"};
+    for (int kind = 0; kind < 8; ++kind)
         for (int nv : {1, 2}) {
             printf("%s x %d per 24 MFMAs (384 matrix cycles):\n", kn[kind], 48 * nv);
             printf("  16x16x32 independent acc: valu alone %.3f ms, mfma alone %.3f ms, both %.3f ms\n", run<16>(d, 1, iters, nv, kind), run<16>(d, 2, iters, nv, kind), run<16>(d, 3, iters, nv, kind));
