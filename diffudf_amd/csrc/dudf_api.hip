@@ -131,6 +131,10 @@ int forward_common(Ctx& c, const float* theta, const float* x, int train, bool r
     if (use_bf16_sweeps() && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
     if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
+    if (train && dudf_split_fp16()) {                   // running maxima of q_l | A_l | zbar_l (fp16x3 weight-gradient GEMM)
+        hipError_t e = hipMemsetAsync(c.ws + c.lo.ws_amax, 0, (size_t)4 * c.lo.L * sizeof(unsigned), c.st);
+        if (e != hipSuccess) return (int)e;
+    }
     // what the forward sweep has to leave behind: h_l only for training (weight gradients, r_l), cos if any later sweep
     // runs — a value-only query stores nothing, a value+gradient query half of what training does
     a.store_s = train ? 1 : 0; a.store_c = (reverse || train) ? 1 : 0; a.train = train;
@@ -156,6 +160,10 @@ int backward_sweeps(Ctx& c, const float* theta, int have_g) {
     int rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     a.train = 1;
+    if (dudf_split_fp16()) {                            // a backward may run several times per forward: A_l and zbar_l start over
+        hipError_t e = hipMemsetAsync(c.ws + c.lo.ws_amax + c.lo.L, 0, (size_t)2 * c.lo.L * sizeof(unsigned), c.st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (have_g) {
         if ((rc = run_sweep(SWEEP_ADJ_FWD, c.lo, a, c.st))) return rc;
     } else {

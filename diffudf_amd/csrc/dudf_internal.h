@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   wimg   bf16x3 images of W_l, then of W_l^T, in A-fragment order (dudf_sweep_bf16.hip)
 //   wimg16 fp16 hi/lo images of 2^k_l W_l, then of 2^k_l W_l^T (same order, two pieces; "fp16x3" split)
 //   wsc    [2][L-1]: 2^-k_l (what the accumulators of matrix l are multiplied with), then 2^k_l
-//   amax   [4][L] uint: bit patterns of max |q_l|, |A_l|, |zbar_l| over all columns of the step (fp16x3 weight-gradient GEMM)
+//   amax   [4][L] uint: bit patterns of max |q_l|, |A_l|, |zbar_l|, |h_l| (Hessian quads) over all columns of the step (fp16x3 weight-gradient GEMM)
 //   per column: x4 [np][4] = layer-1 B operand (x,1 | e_k,0), y [np], g [np][4] (a_0 rows), ybar [np], gbar [np][4]
 //   stash arrays, each [L][H/4][np][4]:  element (layer li, feature f, column p) lives at
 //       ((li*(H/4) + f/4)*np + p)*4 + f%4
@@ -123,7 +123,7 @@ struct SweepArgs {
     const char* wimg_f; const char* wimg_t;   // bf16x3 weight images (forward / transposed), dudf_sweep_bf16.hip
     const char* wimg16_f; const char* wimg16_t;   // fp16 hi/lo weight images, scaled by 2^k_l per matrix
     const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l
-    unsigned* amax;           // [4][L]: running maxima of |q_l|, |A_l|, |zbar_l| (bit patterns), or nullptr
+    unsigned* amax;           // [4][L]: running maxima of |q_l|, |A_l|, |zbar_l|, |h_l| of the quads (bit patterns), or nullptr
     int split;                // 0: bf16x6 everywhere; 1: fp16x3 where it is built (DUDF_SPLIT)
     const float* x4;          // [np][4]: layer-1 B operand per column
     float* y; float* g;       // [np], [np][4]

@@ -105,9 +105,11 @@ __device__ __forceinline__ void dma_wait() {
 // One sweep over one 64-column tile.  `seed` replaces the per-column operand the prologue would read from HBM when
 // the caller already has it in registers (fused step kernel: gbar[q] for SWEEP_ADJ_FWD, ybar for SWEEP_ADJ_REV);
 // `res` returns what the tail produced: y in [0] (SWEEP_FWD, every lane), the a_0 rows in [0..2] (SWEEP_REV, lanes < 16).
+// `tmax`: running max |.| of what the tails store for the weight-gradient GEMM (dudf_sweep_common.h, amax_row) — here one
+// value for all layers of the sweep (an upper bound per layer is all the fp16x3 GEMM's scale needs).
 template <int H, int SW, int FL, bool SEEDED = false>
 __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, float* lds, unsigned& gc, float seed,
-                                           f32x4& res) {
+                                           f32x4& res, float& tmax) {
     using G = Geo<H>;
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);
@@ -156,7 +158,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
                     acc = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
                 }
                 if (T < G::NT - 2) {
-                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, o3, ub, vo, isv);
+                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, o3, ub, vo, isv, tmax);
                 } else if (T == G::NT - 2) {
                     pend.acc0 = acc; pend.o1a = o1; pend.o2a = o2; pend.o3a = o3; pend.ub0 = ub;
                 } else {
@@ -223,8 +225,8 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
                     // freely interleavable region
                     __builtin_amdgcn_sched_barrier(0);
                     // tail of the previous chunk's two tiles (the previous layer's last two when r == 0)
-                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv);
-                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv);
+                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv, tmax);
+                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv, tmax);
                     if (r == 0) { in[G::NT - 2] = e0; in[G::NT - 1] = e1; }
                     else { nxt[2 * r - 2] = e0; nxt[2 * r - 1] = e1; }
                 };
@@ -261,8 +263,8 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
             for (int T = 0; T < G::NT - 2; ++T) in[T] = nxt[T];
         }
         // flush the last pending pair
-        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv);
-        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv);
+        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv, tmax);
+        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv, tmax);
 
         // ------------------------------ tail ------------------------------
         if constexpr (BS == SWEEP_FWD) {                // y = W_out h_L + b_out (tangent channels: their own dot, unused)
@@ -296,8 +298,17 @@ __global__ __launch_bounds__(64 * NW, Geo<H>::WPSIMD) void sweep_kernel(SweepArg
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
     f32x4 res;
+    float tmax = 0.f;
     for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x)
-        sweep_tile<H, SW, FL>(a, tile, lds, gc, 0.f, res);
+        sweep_tile<H, SW, FL>(a, tile, lds, gc, 0.f, res, tmax);
+    if constexpr (amax_row<SW, FL>() >= 0) {            // one bound for every layer of this operand (fp16x3 weight-gradient GEMM)
+        __shared__ unsigned s_amax;
+        if (threadIdx.x == 0) s_amax = 0u;
+        __syncthreads();
+        atomicMax(&s_amax, __float_as_uint(tmax));
+        __syncthreads();
+        if ((int)threadIdx.x < a.L && a.amax && s_amax) atomicMax(a.amax + amax_row<SW, FL>() * a.L + threadIdx.x, s_amax);
+    }
 }
 
 template <int H>

@@ -42,6 +42,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kMaxAmaxLayers = 64;                     // LDS words of the per-layer running maxima (deeper nets: no fp16x3 wgrad)
 constexpr int NWB = 8;                                 // waves per workgroup: two per SIMD
 constexpr int TILEB = NWB * 16;                        // columns per workgroup pass
 
@@ -213,6 +214,14 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // (1 for the first layer, which runs on the fp32 MFMA) — folded into the bias add of the forward tail
     float unscale = 1.f;
     auto unscale_of = [&](int j) -> float { return a.wsc[kFwdDir ? j : nhid - 1 - j]; };
+    // running max |.| of what this sweep's tails store for the weight-gradient GEMM (q_l, A_l or zbar_l), per layer: lanes
+    // -> one LDS word per layer (ds_max_u32 on the bit patterns: non-negative floats order like integers) -> HBM at kernel end
+    constexpr int kRow = amax_row<SW, FL>();
+    float tmax = 0.f;
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
+    auto publish = [&](int layer) {
+        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax)); tmax = 0.f; }
+    };
     // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {   // forward sweep: b_{layer+1}
@@ -243,14 +252,14 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     auto run_tail = [&](int layer, int kb, const f32x4 z0, const f32x4 z1, const TailOps& o, f32x4& e0, f32x4& e1) {
         const f32x4 zero = {0, 0, 0, 0};
         if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
-            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv);
-            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv);
+            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
+            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
-            e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv);
-            e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv);
+            e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
+            e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
         } else {
-            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv);
-            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv);
+            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv, tmax);
+            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
         }
     };
     auto pin_ops = [&](TailOps& o) {                    // make the compiler wait for these loads HERE
@@ -492,6 +501,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 #endif
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
                 if constexpr (SP) unscale = unscale_of(j);
+                publish(lin);                                           // every tail of layer `lin` has run
                 run_tail(lnx, 0, acc[0], acc[1], ops_cur, fin0, fin1);
                 split(fin0, fin1, nb);
                 if constexpr (HS) load_after_next(ops_cur);
@@ -546,6 +556,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 for (int t = 0; t < 4; ++t) accg = mfma16(w1v[t], e1[t], accg);
             }
         }
+        publish(lin);
         if constexpr (BS == SWEEP_FWD) {
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
@@ -561,6 +572,9 @@ template <int H, int SW, int FL, int SP = 0>
 __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
+    constexpr int kRow = amax_row<SW, FL>();
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
+    if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }   // (sweep_tile_b starts with a barrier)
     if constexpr (SP != 0 && base_of(SW) == SWEEP_FWD) {     // b_1 .. b_L behind the three weight buffers (read by the tails)
         float* lb = reinterpret_cast<float*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
         for (int i = threadIdx.x; i < a.L * H; i += 64 * NWB) {
@@ -579,6 +593,13 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
         sweep_tile_b<H, SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && blockIdx.x == 100 && g == g0);
+    if constexpr (kRow >= 0) {
+        __syncthreads();
+        if ((int)threadIdx.x < a.L && (int)threadIdx.x < kMaxAmaxLayers && a.amax) {
+            const unsigned v = lds_amax[threadIdx.x];
+            if (v) atomicMax(a.amax + kRow * a.L + threadIdx.x, v);
+        }
+    }
 }
 // Two code generations of the same body.  The packed fp32 instructions (v_pk_fma_f32 ...) halve the vector-ALU issue
 // slots of a tail, but they do not execute beside the SIMD partner's MFMAs (tools/micro/coissue.hip: 48 v_pk_fma_f32 +
@@ -689,7 +710,7 @@ constexpr int kMaxLdsBiasLayers = 32;                  // fp16x3 forward sweep: 
 template <int H>
 int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoB<H>;
-    const size_t smem = 3 * G::CHUNKB;
+    const size_t smem = 3 * G::CHUNKB + kMaxAmaxLayers * sizeof(unsigned);   // + the per-layer running maxima
     if (a.ntiles <= 0) return 0;
     const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;
     int grid = ntb < 256 ? ntb : 256;                  // one resident 8-wave workgroup per CU
@@ -851,7 +872,10 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     float part = 0.f;                                  // forward: y partial sums; reverse: df/dx accumulator
     f32x4 accg = {0, 0, 0, 0};
     // ---- the elementwise tails of all 32 tiles of `layer` (operands one pair ahead), stash stores, output stage ----
+    constexpr int kRow = amax_row<SW, FL>();
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
     auto tail_burst = [&](int layer, bool last) {
+        float tmax = 0.f;
         // operand ring: the stash operands of tile T + PD are requested when tile T has been consumed.  One tile of tail is
         // ~100 instructions, an HBM round trip ~2 us: with the operands only one tile ahead the burst waited for memory at
         // every tile (it took about as long as the layer's whole k-loop); the forward sweep only reads its bias (cached).
@@ -868,7 +892,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             const int s = T % PD;
             f32x4 z = acc[T];
             if constexpr (SW == SWEEP_FWD) z += bs[s];
-            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, true);
+            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, true, tmax);
             if (T + PD < G::NT) ld(T + PD, s);
             if (last) {
                 if constexpr (SW == SWEEP_FWD) {
@@ -882,6 +906,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             }
             acc[T] = f32x4{0, 0, 0, 0};
         }
+        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax)); }
     };
     // ---- first layer (fp32, K = 3): pre-activations / incoming adjoints of the 32 tiles, then their tails ----
     {
@@ -1008,6 +1033,9 @@ template <int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_w[];
     unsigned gc = 0;
+    constexpr int kRow = amax_row<SW, FL>();
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_w + 3 * GeoW::CHUNKB);
+    if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }
     // A/B knob (off by default): odd workgroups start (a.prio >> 8) x 1024 cycles late.  A layer of this kernel is a compute
     // phase (the k-loop, 117 k cycles at 125 k points, matrix pipe 84 % busy) followed by a memory phase (the tail burst,
     // 25-45 k cycles); putting the two halves of the chip half a layer out of step buys only 1.3 % on the step: the burst
@@ -1021,11 +1049,18 @@ __global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
         sweep_tile_w<SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_w, gc);
+    if constexpr (kRow >= 0) {
+        __syncthreads();
+        if ((int)threadIdx.x < a.L && (int)threadIdx.x < kMaxAmaxLayers && a.amax) {
+            const unsigned v = lds_amax[threadIdx.x];
+            if (v) atomicMax(a.amax + kRow * a.L + threadIdx.x, v);
+        }
+    }
 }
 
 int launch_w(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoW;
-    const size_t smem = 3 * G::CHUNKB;
+    const size_t smem = 3 * G::CHUNKB + kMaxAmaxLayers * sizeof(unsigned);
     if (a.ntiles <= 0) return 0;
     const int ntb = (a.ntiles * TILE + TILEB - 1) / TILEB;
     const int grid = ntb < 256 ? ntb : 256;

@@ -132,9 +132,23 @@ __constant__ unsigned kJetLane[16] = {
     jet_word(6, 1, 9, 2, 15, 0, 2, 2, 1, 0, 1),                                        // rtt: tt*r + rt*t ; t t r / 2
     jet_word(15, 0, 15, 0, 15, 0, 0, 0, 0, 0, 0)};                                     // spare: stays zero
 
+// Which of the wgrad operands a sweep's tail produces (row of SweepArgs::amax), or -1: the fp16x3 weight-gradient GEMM
+// scales q_l, A_l, zbar_l per layer by a power of two taken from max |.| over all columns, so the tails keep a running
+// maximum of what they store (2 v_max3_f32 per tile), published per layer through LDS and once per workgroup to HBM.
+template <int SW, int FL>
+constexpr int amax_row() {
+    return SW == SWEEP_FWD_H ? ((FL & 1) ? 3 : -1)      // h | hdot^k: the tangent channels are not bounded by 1 (plain columns: |h| <= 1)
+         : (base_of(SW) == SWEEP_REV && SW != SWEEP_FWD_J) ? ((FL & 1) ? 0 : -1)
+         : base_of(SW) == SWEEP_ADJ_FWD ? 1
+         : base_of(SW) == SWEEP_ADJ_REV ? 2 : -1;
+}
+__device__ __forceinline__ void dudf_track(float& tmax, const f32x4 v) {
+    tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 template <int SW, int FL>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
-                                          unsigned vo, bool isv) {
+                                          unsigned vo, bool isv, float& tmax) {
     f32x4 out;
     if constexpr (SW == SWEEP_FWD) {
         f32x4 s, c;
@@ -227,6 +241,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         DUDF_ST(a.Z, ub, vo, out);
     }
+    if constexpr (amax_row<SW, FL>() >= 0) dudf_track(tmax, out);
     return out;
 }
 

@@ -42,6 +42,7 @@ struct WgradArgs {
     int j0, nj;                         // hidden matrices [j0, j0 + nj) of this launch (matrix j = layer l = j + 2); grid.x = nj
     int Hs;                             // real layer width; the kernels' template H is the output TILE (<= 256):
                                         // blockIdx.z walks the (Hs/H)^2 tiles of a wider layer
+    const unsigned* amax;               // [4][L] bit patterns of max |q_l|, |A_l|, |zbar_l| over all columns (fp16x3 kernel)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -412,17 +413,36 @@ extern "C" int dudf_dbg_wstamps(unsigned long long* out) { return (int)hipMemcpy
 #else
 #define DUDF_WSTAMP(i) do { } while (0)
 #endif
-template <int H, int VAR>
+// SP = 1: the fp16 hi/lo split ("fp16x3": products hi*hi + hi*lo + lo*hi, see dudf_sweep_bf16.hip) — half the MFMAs, two
+// pieces instead of three to convert, write and read back.  fp16's range is bought with per-layer powers of two: the
+// sweeps leave max |q_l|, |A_l|, |zbar_l| over all columns in `amax` (|s_l| <= 1); each operand is scaled so that its
+// largest element lands below 2^15, the two pairs of a layer (q A^T and zbar s^T accumulate into the same registers) are
+// brought to a common product scale 2^P, and the accumulators are multiplied by 2^-P at the end.  Elements more than 2^16
+// below their tensor's maximum lose relative (not absolute) accuracy: they are fp16 subnormals, which v_cvt_pk_f16_f32
+// produces and the MFMA honours (profiles/r03_f16_split_facts.txt).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int dudf_exp_above(unsigned bits) {     // e with |v| < 2^e, clamped to a range that keeps every scale finite
+    const int e = (int)((bits >> 23) & 255u) - 126;
+    return e < -40 ? -40 : (e > 60 ? 60 : e);
+}
+__device__ __forceinline__ float dudf_pow2(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+
+template <int H, int VAR, int SP = 0>
 __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     using W = WG<H>;
     static_assert(H == 256, "256 x 256 output tiles");
+    constexpr int NPC = SP ? 2 : 3;                         // pieces per operand
     constexpr int NW_ = W::WO * W::WI;
     constexpr int FQ = H / 4;
     constexpr int HALFB = 32 * 16 + 16;                     // 32 features x 8 columns of a block, +16: the second column half
     constexpr int BLKB = 2 * HALFB;                         //   must not sit 512 B = 0 banks after the first (ds_write_b64)
     constexpr int PIECEB = (H / 32) * BLKB;                 // 8.25 KiB
-    constexpr int OPERB = 3 * PIECEB;                       // 24 KiB
-    constexpr int BUFB = 2 * OPERB;                         // 48 KiB
+    constexpr int OPERB = NPC * PIECEB;                     // 24 KiB (16.5)
+    constexpr int BUFB = 2 * OPERB;                         // 48 KiB (33)
     extern __shared__ __attribute__((aligned(16))) char ldsb[];     // [2 buffers][X | Y][h | m | l][feature][16 columns]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -471,6 +491,21 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     f32x4 bacc = {0.f, 0.f, 0.f, 0.f};                                    // bias gradient partial sums (X operand, zbar pair)
     const float* P0 = p_oper ? Y0 : X0;                                   // this wave's operand for the (q, A) / (zbar, s) pair
     const float* P1 = p_oper ? Y1 : X1;
+    // fp16x3: this wave's operand scale for each pair, and the common product scale 2^P of the layer
+    float sc0 = 1.f, sc1 = 1.f, inv_p = 1.f;
+    if constexpr (SP != 0) {
+        const int eq = dudf_exp_above(a.amax[0 * a.L + j + 1]), eA = dudf_exp_above(a.amax[1 * a.L + j]);
+        const int ez = dudf_exp_above(a.amax[2 * a.L + j + 1]);
+        const int esh = dudf_exp_above(a.amax[3 * a.L + j]);             // h | hdot^k of the Hessian quads; plain columns: |h| <= 1 (+ an ulp)
+        const int es = esh > 1 ? esh : 1;
+        const int P1l = 30 - eq - eA, P2l = 30 - ez - es;
+        const int P = (a.have_g && P1l < P2l) ? P1l : P2l;
+        // the pair with the larger admissible product gives the surplus back through its X operand
+        sc0 = p_oper ? dudf_pow2(15 - eA) : dudf_pow2(15 - eq - (P1l - P));
+        sc1 = p_oper ? dudf_pow2(15 - es) : dudf_pow2(15 - ez - (P2l - P));
+        if (!a.have_g) sc0 = sc1;
+        inv_p = dudf_pow2(-P);
+    }
     // Inline asm + hand-counted vmcnt (as in the sweeps): with compiler-visible loads hipcc drains ALL stages in flight
     // (vmcnt(0)) at the loop head.  These twelve loads are the only vector-memory operations of the loop.
     // scalar base (operand, pair, stage: wave-uniform) + this lane's fixed 32-bit byte offset: no per-stage 64-bit address
@@ -546,12 +581,27 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
             bacc += bm * (r.g0 + r.g1 + r.g2 + r.g3);
         }
         const f32x2 v0 = {r.g0[f], r.g1[f]}, v1 = {r.g2[f], r.g3[f]};     // four columns of one feature -> 3 x 8 bytes
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (SP != 0) {
+            // t = v 2^k -> hi = fp16(t), lo = fp16(t - hi): the residual as ONE v_fma_mix_f32 (v * 2^k - hi, exact; reads the
+            // fp16 half in place and issues beside the SIMD partner's MFMAs like v_fma_f32 — tools/micro/coissue.hip)
+            const float scl = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pair_of(it) ? sc1 : sc0)));
+            const f16x2 h0 = __builtin_convertvector(v0 * scl, f16x2), h1 = __builtin_convertvector(v1 * scl, f16x2);
+            f32x2 r0, r1;
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0.x) : "v"(v0.x), "s"(scl), "v"(h0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r0.y) : "v"(v0.y), "s"(scl), "v"(h0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r1.x) : "v"(v1.x), "s"(scl), "v"(h1));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1.y) : "v"(v1.y), "s"(scl), "v"(h1));
+            const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
+            *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            *reinterpret_cast<u32x2*>(dst + PIECEB) = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+            return;
+        }
         const unsigned h0 = cvt_pk(v0), h1 = cvt_pk(v1);
         const f32x2 r0 = v0 - unpack(h0), r1 = v1 - unpack(h1);
         const unsigned m0 = cvt_pk(r0), m1 = cvt_pk(r1);
         const f32x2 q0 = r0 - unpack(m0), q1 = r1 - unpack(m1);
         const unsigned l0 = cvt_pk(q0), l1 = cvt_pk(q1);
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(dst + PIECEB) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(dst + 2 * PIECEB) = u32x2{l0, l1};
@@ -562,13 +612,13 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     };
     // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
     const int c_lane = (lane >> 5) * HALFB + (lane & 31) * 16;
-    auto fragA = [&](const char* buf, int m, int pc) -> bf16x8 {
-        if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }     // timing only: no LDS read
-        return *reinterpret_cast<const bf16x8*>(buf + pc * PIECEB + (wo * W::MT + m) * BLKB + c_lane);
+    auto fragA = [&](const char* buf, int m, int pc) -> u32x4 {
+        if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { u32x4 z; asm volatile("" : "=v"(z)); return z; }     // timing only: no LDS read
+        return *reinterpret_cast<const u32x4*>(buf + pc * PIECEB + (wo * W::MT + m) * BLKB + c_lane);
     };
-    auto fragB = [&](const char* buf, int n, int pc) -> bf16x8 {
-        if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
-        return *reinterpret_cast<const bf16x8*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
+    auto fragB = [&](const char* buf, int n, int pc) -> u32x4 {
+        if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { u32x4 z; asm volatile("" : "=v"(z)); return z; }
+        return *reinterpret_cast<const u32x4*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
     };
 
     if constexpr (CS) {
@@ -635,15 +685,15 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                 if (it + 4 < nit) load_raw_plain(it + 4, r);
             }
         }
-        bf16x8 af[W::MT][3], bn[3];
+        u32x4 af[W::MT][NPC], bn[NPC];
 #pragma unroll
         for (int m = 0; m < W::MT; ++m)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) af[m][pc] = fragA(buf, m, pc);
+            for (int pc = 0; pc < NPC; ++pc) af[m][pc] = fragA(buf, m, pc);
         DUDF_WSTAMP(1);
         if constexpr (!IL) {
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, 0, pc);
+            for (int pc = 0; pc < NPC; ++pc) bn[pc] = fragB(buf, 0, pc);
         }
 #pragma unroll
         for (int n = 0; n < W::NTL; ++n) {
@@ -651,31 +701,42 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                 // this group's B fragments, then slice n of the next stage's split (its VALU covers the read latency: no
                 // second fragment set in registers), then this group's MFMAs
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n, pc);
+                for (int pc = 0; pc < NPC; ++pc) bn[pc] = fragB(buf, n, pc);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (HOT && !(DBG & 1)) { if (n == 0) wait_raw(r, std::integral_constant<int, 8>{}); }
                 if constexpr (!(DBG & 8)) { if (more) split_slice(it + 1, r, n, bnext); }
                 __builtin_amdgcn_sched_barrier(0);
                 DUDF_WSTAMP(2 + 2 * n);
             }
-            const bf16x8 bh = bn[0], bmid = bn[1], bl = bn[2];
+            u32x4 bc[NPC];
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) bc[pc] = bn[pc];
             if constexpr (!IL) {
                 if (n + 1 < W::NTL) {
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) bn[pc] = fragB(buf, n + 1, pc);
+                    for (int pc = 0; pc < NPC; ++pc) bn[pc] = fragB(buf, n + 1, pc);
                     __builtin_amdgcn_sched_barrier(0x76);        // LDS reads and MFMAs keep their order: fragments one block ahead
                 }
             }
 #pragma unroll
             for (int m = 0; m < W::MT; ++m) {
-                if constexpr ((DBG & 4) != 0) { asm volatile("" :: "v"(af[m][0]), "v"(af[m][1]), "v"(af[m][2]), "v"(bh), "v"(bmid), "v"(bl)); continue; }
+                if constexpr ((DBG & 4) != 0) { asm volatile("" :: "v"(af[m][0]), "v"(af[m][1]), "v"(bc[0]), "v"(bc[1])); continue; }
                 f32x16 c = acc[m][n];
-                c = mfma_bf16(af[m][1], bmid, c);                 // smallest terms first
-                c = mfma_bf16(af[m][2], bh, c);
-                c = mfma_bf16(af[m][0], bl, c);
-                c = mfma_bf16(af[m][1], bh, c);
-                c = mfma_bf16(af[m][0], bmid, c);
-                c = mfma_bf16(af[m][0], bh, c);
+                if constexpr (SP != 0) {                          // smallest terms first: lo*hi, hi*lo, hi*hi
+                    auto H8 = [](u32x4 v) { return __builtin_bit_cast(f16x8, v); };
+                    c = mfma_f16(H8(af[m][1]), H8(bc[0]), c);
+                    c = mfma_f16(H8(af[m][0]), H8(bc[1]), c);
+                    c = mfma_f16(H8(af[m][0]), H8(bc[0]), c);
+                } else {
+                    auto B8 = [](u32x4 v) { return __builtin_bit_cast(bf16x8, v); };
+                    const bf16x8 bh = B8(bc[0]), bmid = B8(bc[1]), bl = B8(bc[NPC - 1]);
+                    c = mfma_bf16(B8(af[m][1]), bmid, c);             // smallest terms first
+                    c = mfma_bf16(B8(af[m][NPC - 1]), bh, c);
+                    c = mfma_bf16(B8(af[m][0]), bl, c);
+                    c = mfma_bf16(B8(af[m][1]), bh, c);
+                    c = mfma_bf16(B8(af[m][0]), bmid, c);
+                    c = mfma_bf16(B8(af[m][0]), bh, c);
+                }
                 acc[m][n] = c;
             }
             if constexpr (IL) __builtin_amdgcn_sched_barrier(0);
@@ -760,7 +821,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) {
                     const int i = (wi * W::NTL + n) * 32 + l32;
-                    atomicAdd(dW + (int64_t)o * a.Hs + i, acc[m][n][e]);
+                    atomicAdd(dW + (int64_t)o * a.Hs + i, SP != 0 ? acc[m][n][e] * inv_p : acc[m][n][e]);
                 }
             }
         if (p_oper == 0 && i_off == 0) {                          // bias gradient: sum the four column groups of a quad first
@@ -779,6 +840,10 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
 template <int H, int VAR>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_bf16p_kernel(WgradArgs a) {
     wgrad_hidden_bf16p_body<H, VAR>(a);
+}
+template <int H, int VAR>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_f16p_kernel(WgradArgs a) {
+    wgrad_hidden_bf16p_body<H, VAR, 1>(a);
 }
 
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
@@ -905,6 +970,18 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                 // MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe).  The plain producer-lane
                 // order and the static-priority variants (round-2 experiments, measured no faster) are no longer built.
                 static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 9; }();
+                if (dudf_split_fp16() && a.amax && a.L <= 64 && var == 9) {       // fp16x3 (DUDF_SPLIT=bf16 keeps bf16x6)
+                    static bool attr4 = false;
+                    const size_t smem_h = 3 * (size_t)(2 * 2 * (H / 32) * 2 * (32 * 16 + 16)) + 512;   // three buffers x (X | Y) x 2 pieces + the flags
+                    if (!attr4) {
+                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_f16p_kernel<H, 9>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
+                        if (e != hipSuccess) return (int)e;
+                        attr4 = true;
+                    }
+                    hipLaunchKernelGGL((wgrad_hidden_f16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_h, st, a);
+                    return (int)hipGetLastError();
+                }
                 if (!attr3) {
                     hipError_t e = hipSuccess;
                     const size_t smem_cs = smem_p / 2 * 3 + 512;                     // three buffers + the flags
@@ -945,6 +1022,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.dtheta = dtheta; a.np = lo.np; a.stash_layer = lo.stash_layer;
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.ncols / KT); a.L = lo.L;
     a.have_g = have_g; a.Hs = lo.H;
+    a.amax = reinterpret_cast<const unsigned*>(ws + lo.ws_amax);
     const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
     a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;

@@ -105,7 +105,9 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
     second pass starts with what the first left in flight — and returns the instructions that touch a destination
     register of a load still in flight (must be none), the loads per pass and the loads in flight across the back edge."""
     txt = open(asm_path).read()
-    if kernel == "q":          # the fragment-prefetching kernel: two register sets (8 loads) per pass of its two-stage loop
+    if kernel == "f16":        # the fp16x3 build of the same body
+        m = re.search(r"^(_ZN\w*wgrad_hidden_f16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
+    elif kernel == "q":        # the fragment-prefetching kernel: two register sets (8 loads) per pass of its two-stage loop
         m = re.search(r"^(_ZN\w*wgrad_hidden_bf16q_kernelILi256E\w*):", txt, re.M)
     else:
         m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
@@ -119,7 +121,7 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
         else:
             cur.append(t)
     blocks.append((name, cur))
-    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= 90
+    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= (60 if kernel == "f16" else 90)
            and any(x.startswith("global_load_dwordx4") for x in b)]
     assert len(hot) == 1, [n for n, _ in hot]
     name, blk = hot[0]

@@ -27,6 +27,36 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
+def disambiguate(P64, x, nrm, sdf, alpha=100.0):
+    """`loss_s1` is a sum of ABSOLUTE values: |y| on the surface, |tdf - y| off it, | |grad f| - tau | everywhere
+    (reference src/loss_functions.py:9-22, :136-137).  A point that sits within fp32 noise of one of those kinks gets the
+    opposite sign of a whole 1/N cotangent in fp32 and in fp64 — at 100 000 points a handful always do, and ONE flip moves
+    db_out by 6e-5 of its size (measured; the reference's own fp32 run flips the same way against its fp64 run).  Such
+    points say nothing about the kernels, so they are replaced by copies of their stratum's first unambiguous point: same
+    batch size, same on / far / near thirds."""
+    n = x.shape[0]
+    Pt = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in P64]
+    ys, gs = [], []
+    with torch.no_grad():
+        for lo in range(0, n, CHUNK):
+            y, g, _ = O.query(Pt, torch.from_numpy(x[lo:lo + CHUNK].astype(np.float64)), xp=torch)
+            ys.append(y.numpy()); gs.append(g.numpy())
+    y, g = np.concatenate(ys), np.concatenate(gs)
+    u = sdf[:, 0].astype(np.float64)
+    tan = np.tanh(alpha * u)
+    tau = np.abs(tan + u * alpha * (1.0 - tan * tan))
+    gn = np.linalg.norm(g, axis=1)
+    margin_y = np.where(u == 0, np.abs(y), np.abs(u * tan - y))
+    bad = (margin_y < 2e-5 * np.abs(y).max()) | (np.abs(gn - tau) < 2e-4 * gn.max())
+    x, nrm, sdf = x.copy(), nrm.copy(), sdf.copy()
+    third = n // 3
+    for a, b in ((0, third), (third, 2 * third), (2 * third, n)):
+        good = a + int(np.flatnonzero(~bad[a:b])[0])
+        idx = a + np.flatnonzero(bad[a:b])
+        x[idx], nrm[idx], sdf[idx] = x[good], nrm[good], sdf[good]
+    return x, nrm, sdf, int(bad.sum())
+
+
 def oracle_full(P64, x, nrm, sdf, n):
     """loss terms (4,) and flat d(theta) of the whole batch, fp64, chunked over points."""
     Pt = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in P64]
@@ -50,6 +80,8 @@ def test_step_against_oracle_at_full_size(hidden, n):
     P32 = synth.siren_params(hidden, seed=123)
     P64 = [(w.astype(np.float64), b.astype(np.float64)) for w, b in P32]
     x, nrm, sdf = synth.training_batch(n, seed=124)
+    x, nrm, sdf, n_amb = disambiguate(P64, x, nrm, sdf)
+    assert n_amb < n // 100
     th = torch.from_numpy(synth.flatten_params(P32)).cuda()
     xd, nd, sd = [torch.from_numpy(a).cuda() for a in (x, nrm, sdf.reshape(-1))]
     cfg = hip.make_cfg(hidden)
@@ -88,8 +120,8 @@ def test_step_against_oracle_at_full_size(hidden, n):
         offs.append((o, o + w_.size)); o += w_.size
         offs.append((o, o + b_.size)); o += b_.size
     per = max(rel(dth[a:b], g_ref[a:b]) for a, b in offs)
-    print(f"full size {H}x{L} n={n}: terms {et:.2e} dtheta {ed:.2e} (worst single tensor {per:.2e}); stash "
+    print(f"full size {H}x{L} n={n} ({n_amb} points at a kink of the loss replaced): terms {et:.2e} dtheta {ed:.2e} (worst single tensor {per:.2e}); stash "
           + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     assert et < TOL_TERM
     assert ed < TOL_DTHETA
-    assert per < 5 * TOL_DTHETA
+    assert per < TOL_DTHETA
