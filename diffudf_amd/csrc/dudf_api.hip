@@ -41,6 +41,11 @@ bool dudf_split_fp16() {
     static const bool on = [] { const char* e = getenv("DUDF_SPLIT"); return !(e && e[0] == 'b'); }();
     return on;
 }
+// which plain-column sweeps run fp16x3: DUDF_SPLIT_SWEEPS = bit mask (bit 0 forward .. bit 3 adjoint reverse; A/B testing)
+int dudf_split_mask() {
+    static const int m = [] { const char* e = getenv("DUDF_SPLIT_SWEEPS"); return e ? atoi(e) & 15 : 15; }();
+    return dudf_split_fp16() ? m : 0;
+}
 
 namespace {
 
@@ -65,7 +70,8 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.wimg16_t = a.wimg16_f + (size_t)(lo.L - 1) * lo.H * lo.H * 4;
     a.wsc = ws + lo.ws_wsc;
     a.amax = reinterpret_cast<unsigned*>(ws + lo.ws_amax);
-    a.split = dudf_split_fp16() ? 1 : 0;
+    a.ebound = (lo.ws_ebound != lo.ws_amax) ? ws + lo.ws_ebound : nullptr;
+    a.split = dudf_split_mask();
     a.x4 = ws + lo.ws_x4; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
     a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.ZS = ws + lo.ws_ZS; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R;
     a.E = ws + lo.ws_E; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z;

@@ -32,6 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   wimg   bf16x3 images of W_l, then of W_l^T, in A-fragment order (dudf_sweep_bf16.hip)
 //   wimg16 fp16 hi/lo images of 2^k_l W_l, then of 2^k_l W_l^T (same order, two pieces; "fp16x3" split)
 //   wsc    [2][L-1]: 2^-k_l (what the accumulators of matrix l are multiplied with), then 2^k_l
+//   ebound [L][np]: max over the features of |e_l| per column (the adjoint forward sweep leaves it for the fp16x3 adjoint
+//          reverse sweep, which scales each column of zbar_l = w0 c_l hbar_l - e_l by a power of two before it knows it)
 //   amax   [4][L] uint: bit patterns of max |q_l|, |A_l|, |zbar_l|, |h_l| (Hessian quads) over all columns of the step (fp16x3 weight-gradient GEMM)
 //   per column: x4 [np][4] = layer-1 B operand (x,1 | e_k,0), y [np], g [np][4] (a_0 rows), ybar [np], gbar [np][4]
 //   stash arrays, each [L][H/4][np][4]:  element (layer li, feature f, column p) lives at
@@ -54,7 +56,7 @@ struct DudfLayout {
     // theta
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
-    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
+    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_ebound, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
     int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array
     size_t total_bytes;
@@ -90,6 +92,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_wimg16 = take((int64_t)(L - 1) * H * H * 2);    // fp16 hi/lo images of W_l and W_l^T: 2 x 4 bytes per weight
     lo->ws_wsc = take(2 * (int64_t)(L > 1 ? L - 1 : 1));
     lo->ws_amax = take(4 * (int64_t)L);
+    lo->ws_ebound = query_only ? lo->ws_amax : take((int64_t)L * lo->np);   // [L][np]: max_f |e_l[f][column]| (fp16x3 adjoint reverse sweep)
     lo->ws_x4 = take(4 * lo->np);
     lo->ws_y = take(lo->np); lo->ws_g = take(4 * lo->np);
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
@@ -124,7 +127,8 @@ struct SweepArgs {
     const char* wimg16_f; const char* wimg16_t;   // fp16 hi/lo weight images, scaled by 2^k_l per matrix
     const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l
     unsigned* amax;           // [4][L]: running maxima of |q_l|, |A_l|, |zbar_l|, |h_l| of the quads (bit patterns), or nullptr
-    int split;                // 0: bf16x6 everywhere; 1: fp16x3 where it is built (DUDF_SPLIT)
+    float* ebound;            // [L][np]: per layer and column, max over features of |e_l| (written by SWEEP_ADJ_FWD), or nullptr
+    int split;                // bit s: sweep s (SWEEP_FWD .. SWEEP_ADJ_REV) of the plain columns runs the fp16x3 kernel (DUDF_SPLIT)
     const float* x4;          // [np][4]: layer-1 B operand per column
     float* y; float* g;       // [np], [np][4]
     const float* ybar; const float* gbar;
@@ -190,6 +194,7 @@ bool dudf_deterministic();
 // DUDF_SPLIT=bf16 keeps every hidden matmul on the exact three-piece bf16 split (six products); default: the fp16 hi/lo
 // split (three products) where it is built.  Read once.
 bool dudf_split_fp16();
+int dudf_split_mask();
 
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,

@@ -109,7 +109,7 @@ __device__ __forceinline__ void dma_wait() {
 // value for all layers of the sweep (an upper bound per layer is all the fp16x3 GEMM's scale needs).
 template <int H, int SW, int FL, bool SEEDED = false>
 __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, float* lds, unsigned& gc, float seed,
-                                           f32x4& res, float& tmax) {
+                                           f32x4& res, TailTrack& tmax) {
     using G = Geo<H>;
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);
@@ -298,14 +298,14 @@ __global__ __launch_bounds__(64 * NW, Geo<H>::WPSIMD) void sweep_kernel(SweepArg
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned gc = 0;                                   // running chunk counter: LDS buffer parity
     f32x4 res;
-    float tmax = 0.f;
+    TailTrack tmax;
     for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x)
         sweep_tile<H, SW, FL>(a, tile, lds, gc, 0.f, res, tmax);
     if constexpr (amax_row<SW, FL>() >= 0) {            // one bound for every layer of this operand (fp16x3 weight-gradient GEMM)
         __shared__ unsigned s_amax;
         if (threadIdx.x == 0) s_amax = 0u;
         __syncthreads();
-        atomicMax(&s_amax, __float_as_uint(tmax));
+        atomicMax(&s_amax, __float_as_uint(tmax.t));
         __syncthreads();
         if ((int)threadIdx.x < a.L && a.amax && s_amax) atomicMax(a.amax + amax_row<SW, FL>() * a.L + threadIdx.x, s_amax);
     }

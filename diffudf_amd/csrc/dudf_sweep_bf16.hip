@@ -33,6 +33,23 @@
 #include "dudf_sweep_common.h"
 #include <type_traits>
 
+// tuning knobs of sweep_tile_b (A/B builds through tools/build_dbg.sh; the expressions are evaluated inside the template)
+#ifndef DUDF_TP
+#define DUDF_TP (SP ? 2 : 1)                 // tiles per MFMA trip (chains interleaved)
+#endif
+#ifndef DUDF_AD
+#define DUDF_AD 4
+#endif
+#ifndef DUDF_ONESET
+#define DUDF_ONESET 0
+#endif
+#ifndef DUDF_TAILSEQ
+#define DUDF_TAILSEQ 0
+#endif
+#ifndef DUDF_TAIL_TOP
+#define DUDF_TAIL_TOP (SP != 0 && BS == SWEEP_FWD)   // early half: tail in front of the step's DMA pieces
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -193,7 +210,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                                              const bool stamp_on = false) {
     using G = GeoB<H, SP>;
     constexpr int NPC = G::NPC;
-    static_assert(SP == 0 || SW == SWEEP_FWD, "fp16x3: built for the forward sweep (|h_l| <= 1 needs no activation scale)");
+    static_assert(SP == 0 || SW <= SWEEP_ADJ_REV, "fp16x3: plain columns");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -214,13 +231,43 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // (1 for the first layer, which runs on the fp32 MFMA) — folded into the bias add of the forward tail
     float unscale = 1.f;
     auto unscale_of = [&](int j) -> float { return a.wsc[kFwdDir ? j : nhid - 1 - j]; };
+    // fp16x3, B operand.  The forward sweep's is h_l = sin(.): |h| <= 1 fits fp16 as it stands (small values keep an absolute
+    // error of 2^-25: fp16 subnormals are honoured).  The other sweeps' operands (q_l, A_l, zbar_l) have no a-priori size, so
+    // every COLUMN gets its own power of two `sb`, fixed when the previous layer's accumulators are final — before any of
+    // its tails has run — from a bound: |q_l| <= w0 max_f |a_l|, |A_l| <= w0 max_f |Q_l|, |zbar_l| <= w0 max_f |hbar_l| +
+    // max_f |e_l| (the last term left per layer and column by the adjoint forward sweep, SweepArgs::ebound).  The scaled
+    // column stays below 2^15; a bound that is loose by 2^m costs m of the 16 bits by which fp16's subnormal floor sits
+    // below fp32's half ulp of the column maximum.  `unscale` (per lane = per column) turns the accumulators of the matrix
+    // that consumed the scaled operand back into true values: 2^-k_j / sb.
+    constexpr bool kColScale = SP != 0 && BS != SWEEP_FWD;
+    constexpr bool kTrackE = SP != 0 && BS == SWEEP_ADJ_FWD;   // (the fp16x3 adjoint reverse sweep therefore needs the fp16x3 adjoint forward one)
+    float sb = 1.f, inv_sb = 1.f;                       // scale of the B operand being built (tails of `prev`) and its inverse
+    auto colmax = [&](const f32x4 (&t)[G::NT]) -> float {      // max |.| over the 16 tiles' registers and the 4 lane quarters: per column
+        float m = 0.f;
+#pragma unroll
+        for (int T = 0; T < G::NT; ++T) dudf_track(m, t[T]);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        return fmaxf(m, __shfl_xor(m, 32));
+    };
+    auto set_scale = [&](float amax_true, float extra) {       // extra: the bound of what the tail adds (adjoint reverse: e_l)
+        const float bound = a.w0 * amax_true + extra;
+        unsigned E = (__float_as_uint(bound) >> 23) & 255u;    // bound < 2^(E - 126)
+        E = E < 27u ? 27u : (E > 250u ? 250u : E);             // all-zero (padding) columns, infinities: any finite scale will do
+        sb = __uint_as_float((268u - E) << 23);                // 2^(15 - (E - 126))
+        inv_sb = __uint_as_float((E - 14u) << 23);
+    };
+    auto ebound_of = [&](int layer) -> float {                 // adjoint reverse sweep with df/dx terms: max_f |e_layer| of this column
+        if constexpr (kColScale && BS == SWEEP_ADJ_REV && (FL & 1) != 0) return a.ebound[(int64_t)layer * a.np + p];
+        return 0.f;
+    };
+    float eb_next = 0.f;
     // running max |.| of what this sweep's tails store for the weight-gradient GEMM (q_l, A_l or zbar_l), per layer: lanes
     // -> one LDS word per layer (ds_max_u32 on the bit patterns: non-negative floats order like integers) -> HBM at kernel end
     constexpr int kRow = amax_row<SW, FL>();
-    float tmax = 0.f;
+    TailTrack tmax;
     unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
     auto publish = [&](int layer) {
-        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax)); tmax = 0.f; }
+        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax.t)); tmax.t = 0.f; }
     };
     // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
@@ -257,6 +304,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
             e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
             e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+        } else if constexpr (kColScale) {            // accumulators -> true values first (2^-k_j / sb of the matrix that made them)
+            e0 = epilogue<SW, FL, kTrackE>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv, tmax);
+#if DUDF_TAILSEQ
+            if constexpr (BS == SWEEP_ADJ_FWD) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the pair's temporaries do not fit
+#endif
+            e1 = epilogue<SW, FL, kTrackE>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
         } else {
             e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv, tmax);
             e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
@@ -324,20 +377,39 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // Tail operands: plain columns keep two sets (the next tail's, pinned at the top of the step, and the one after it,
     // loaded right behind the DMA: a full step ahead); the quad variants have a third operand array and no registers
     // for that — one set, refilled right after the tail that consumed it (about 0.8 step ahead).
+    // (the fp16x3 adjoint forward sweep — two loads, two stores and the column scales — fits its registers with one set only)
+    constexpr bool kOneSet = HS || (SP != 0 && BS == SWEEP_ADJ_FWD && DUDF_ONESET);
     TailOps ops_cur, ops_n1;
     u32x4 bp[NPC];                                     // B operand of the current step: bf16 h | m | l, or fp16 hi | lo
     auto split = [&](const f32x4 e0, const f32x4 e1, u32x4 (&o)[NPC]) {
-        if constexpr (SP) split8h(e0, e1, o[0], o[1]);
+        if constexpr (kColScale) split8h(e0 * sb, e1 * sb, o[0], o[1]);
+        else if constexpr (SP) split8h(e0, e1, o[0], o[1]);
         else split8(e0, e1, o[0], o[1], o[2]);
+    };
+    // per layer and column max_f |e_l|: the adjoint forward sweep leaves it for the adjoint reverse sweep's column scale
+    auto store_ebound = [&](int layer) {
+        if constexpr (kTrackE) {
+            if (a.ebound) {
+                float m = fmaxf(tmax.e, __shfl_xor(tmax.e, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (q == 0) a.ebound[(int64_t)layer * a.np + p] = m;
+            }
+            tmax.e = 0.f;
+        }
     };
     f32x4 fin0 = {0, 0, 0, 0}, fin1 = {0, 0, 0, 0};    // fp32 results of pair 0 of the layer after the last matrix
     load_ops(in_layer(0), 0, ops_cur);
-    if constexpr (!HS) load_ops(in_layer(0), 1, ops_n1);
+    if constexpr (!kOneSet) load_ops(in_layer(0), 1, ops_n1);
+    if constexpr (kColScale) {                         // first layer (fp32 MFMA / W_out^T ybar: true values): its column scale
+        const float eb0 = ebound_of(in_layer(0));
+        if (nhid > 0) eb_next = ebound_of(in_layer(1));
+        set_scale(colmax(prev), eb0);
+    }
     {
         f32x4 e0, e1;
         run_tail(in_layer(0), 0, prev[0], prev[1], ops_cur, e0, e1);
         split(e0, e1, bp);
-        if constexpr (HS) load_ops(in_layer(0), 1, ops_cur);
+        if constexpr (kOneSet) load_ops(in_layer(0), 1, ops_cur);
     }
 #pragma unroll
     for (int T = 0; T < G::NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
@@ -357,15 +429,6 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 #endif
     // feed slot: after which tile's MFMAs a wave issues its DMA pieces and operand loads (-1: at the top of the step);
     // tail slot: after which tile's MFMAs it runs the tail of the next step.  A = waves 0-3, B = waves 4-7 (when `late`).
-#ifndef DUDF_TP
-#define DUDF_TP (SP ? 2 : 1)
-#endif
-#ifndef DUDF_AD
-#define DUDF_AD 4
-#endif
-#ifndef DUDF_TAIL_TOP
-#define DUDF_TAIL_TOP (SP != 0)
-#endif
 #ifndef DUDF_FA
 #define DUDF_FA -1
 #define DUDF_TA 0
@@ -386,7 +449,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 return *reinterpret_cast<const u32x4*>(bpl + (T * NPC + pc) * G::FRAG);
             };
             DUDF_STAMP(0);
-            if constexpr (!HS) ops_cur = ops_n1;
+            if constexpr (!kOneSet) ops_cur = ops_n1;
             pin_ops(ops_cur);
             const bool more = c + 2 < total;
             auto load_after_next = [&](TailOps& o) {                 // operands of tail c+2
@@ -395,7 +458,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             };
             auto feed = [&]() {                                      // this step's DMA pieces, then the operand loads
                 if (more) dma2(chunk_src(c + 2), lds0 + ((gc + 2) % 3) * G::CHUNKB);
-                if constexpr (!HS) load_after_next(ops_n1);          // one full step ahead
+                if constexpr (!kOneSet) load_after_next(ops_n1);          // one full step ahead
             };
             u32x4 nb[NPC];
             // fp16x3: the half that does not multiply first runs its tail at the very top of the step, in front of its DMA
@@ -407,7 +470,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 f32x4 e0, e1;
                 run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
                 split(e0, e1, nb);
-                if constexpr (HS) load_after_next(ops_cur);
+                if constexpr (kOneSet) load_after_next(ops_cur);
                 DUDF_STAMP(3);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -417,7 +480,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
             // chunk DMA on the LDS, one tile of distance does not cover the read latency
             // (fp16x3: FOUR tiles = 12 MFMAs: a tile is only three MFMAs long)
-            constexpr int AD = SP ? DUDF_AD : 2;
+            constexpr int AD = (SP && BS == SWEEP_FWD) ? DUDF_AD : 2;   // (the other fp16x3 sweeps need the registers: two tiles)
             u32x4 an[AD][NPC];
 #pragma unroll
             for (int T = 0; T < AD; ++T)
@@ -489,7 +552,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                     f32x4 e0, e1;
                     run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
                     split(e0, e1, nb);
-                    if constexpr (HS) load_after_next(ops_cur);
+                    if constexpr (kOneSet) load_after_next(ops_cur);
 #ifdef DUDF_MPRIO
                     if (Tl + 1 < G::NT) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -500,11 +563,18 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             __builtin_amdgcn_s_setprio(0);
 #endif
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
-                if constexpr (SP) unscale = unscale_of(j);
+                if constexpr (kColScale) {
+                    // this matrix consumed the operand scaled by sb: its accumulators are 2^k_j sb x the true values
+                    unscale = unscale_of(j) * inv_sb;
+                    const float ebl = eb_next;
+                    if (j + 2 <= nhid) eb_next = ebound_of(in_layer(j + 2));   // a layer ahead: its latency hides behind 8 steps
+                    set_scale(colmax(acc) * unscale, ebl);              // ... and the scale of the operand its tails are about to build
+                } else if constexpr (SP) unscale = unscale_of(j);
                 publish(lin);                                           // every tail of layer `lin` has run
+                store_ebound(lin);
                 run_tail(lnx, 0, acc[0], acc[1], ops_cur, fin0, fin1);
                 split(fin0, fin1, nb);
-                if constexpr (HS) load_after_next(ops_cur);
+                if constexpr (kOneSet) load_after_next(ops_cur);
 #pragma unroll
                 for (int T = 0; T < G::NT; ++T) { prev[T] = acc[T]; acc[T] = f32x4{0, 0, 0, 0}; }
             }
@@ -535,12 +605,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         for (int kb = 0; kb < G::NKB; ++kb) {
             f32x4 e0 = fin0, e1 = fin1;
             if (kb > 0) {
-                if constexpr (!HS) {
+                if constexpr (!kOneSet) {
                     ops_cur = ops_n1;
                     if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_n1);
                 }
                 run_tail(lin, kb, prev[2 * kb], prev[2 * kb + 1], ops_cur, e0, e1);
-                if constexpr (HS) { if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_cur); }
+                if constexpr (kOneSet) { if (kb + 1 < G::NKB) load_ops(lin, kb + 1, ops_cur); }
             }
             if constexpr (BS == SWEEP_FWD) {
                 const f32x4 w0v = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 32 * kb + 4 * q);
@@ -557,6 +627,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             }
         }
         publish(lin);
+        store_ebound(lin);
         if constexpr (BS == SWEEP_FWD) {
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
@@ -729,25 +800,39 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         else                                                                                                \
             hipLaunchKernelGGL((sweep_bf16_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);     \
     } while (0)
-#define DUDF_GO_H(SW, FL)                                                                                   \
+#define DUDF_GO_H(SW, FL, KERNEL, SMEM_MAX, SMEM)                                                           \
     do {                                                                                                    \
         static bool attr_done = false;                                                                      \
-        const size_t smem_h = 3 * GeoB<H, 1>::CHUNKB + (size_t)a.L * H * sizeof(float);   /* + the biases */   \
         if (!attr_done) {                                                                                   \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_f16_np_kernel<H, SW, FL>),         \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,                             \
-                                    (int)(3 * GeoB<H, 1>::CHUNKB + kMaxLdsBiasLayers * H * sizeof(float))); \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<H, SW, FL>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM_MAX));           \
             if (e != hipSuccess) return (int)e;                                                             \
             attr_done = true;                                                                               \
         }                                                                                                   \
-        hipLaunchKernelGGL((sweep_f16_np_kernel<H, SW, FL>), dim3(grid), dim3(G::NTHR), smem_h, st, a);     \
+        hipLaunchKernelGGL((KERNEL<H, SW, FL>), dim3(grid), dim3(G::NTHR), (SMEM), st, a);                  \
     } while (0)
-    if (a.split == 1 && which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {   // fp16x3 (DUDF_SPLIT): the forward sweep of the plain columns
-        if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3);
-        else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2);
-        else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0);
-        else return DUDF_E_BADMODE;
-        return (int)hipGetLastError();
+    // fp16x3 (DUDF_SPLIT, DUDF_SPLIT_SWEEPS): the plain columns' four sweeps
+    if (which <= SWEEP_ADJ_REV && ((a.split >> which) & 1)) {
+        constexpr size_t w3 = 3 * GeoB<H, 1>::CHUNKB;
+        const size_t smem_f = w3 + (size_t)a.L * H * sizeof(float);          // + the biases (forward sweep)
+        constexpr size_t smem_fmax = w3 + kMaxLdsBiasLayers * H * sizeof(float);
+        constexpr size_t smem_o = w3 + kMaxAmaxLayers * sizeof(unsigned);    // + the per-layer running maxima
+        bool done = true;
+        if (which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {
+            if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3, sweep_f16_np_kernel, smem_fmax, smem_f);
+            else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2, sweep_f16_np_kernel, smem_fmax, smem_f);
+            else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0, sweep_f16_np_kernel, smem_fmax, smem_f);
+            else return DUDF_E_BADMODE;
+        } else if (which == SWEEP_REV) {
+            if (a.train) DUDF_GO_H(SWEEP_REV, 1, sweep_f16_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_REV, 0, sweep_f16_kernel, smem_o, smem_o);
+        } else if (which == SWEEP_ADJ_FWD) {
+            DUDF_GO_H(SWEEP_ADJ_FWD, 0, sweep_f16_kernel, smem_o, smem_o);
+        } else if (which == SWEEP_ADJ_REV && (!a.have_e || (a.ebound && ((a.split >> SWEEP_ADJ_FWD) & 1)))) {
+            if (a.have_e) DUDF_GO_H(SWEEP_ADJ_REV, 1, sweep_f16_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_ADJ_REV, 0, sweep_f16_kernel, smem_o, smem_o);
+        } else {
+            done = false;
+        }
+        if (done) return (int)hipGetLastError();
     }
 #undef DUDF_GO_H
     switch (which) {
@@ -875,7 +960,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     constexpr int kRow = amax_row<SW, FL>();
     unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
     auto tail_burst = [&](int layer, bool last) {
-        float tmax = 0.f;
+        TailTrack tmax;
         // operand ring: the stash operands of tile T + PD are requested when tile T has been consumed.  One tile of tail is
         // ~100 instructions, an HBM round trip ~2 us: with the operands only one tile ahead the burst waited for memory at
         // every tile (it took about as long as the layer's whole k-loop); the forward sweep only reads its bias (cached).
@@ -906,7 +991,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             }
             acc[T] = f32x4{0, 0, 0, 0};
         }
-        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax)); }
+        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax.t)); }
     };
     // ---- first layer (fp32, K = 3): pre-activations / incoming adjoints of the 32 tiles, then their tails ----
     {

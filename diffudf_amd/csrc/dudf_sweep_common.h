@@ -142,13 +142,14 @@ constexpr int amax_row() {
          : base_of(SW) == SWEEP_ADJ_FWD ? 1
          : base_of(SW) == SWEEP_ADJ_REV ? 2 : -1;
 }
+struct TailTrack { float t = 0.f, e = 0.f; };          // running max |.| of the wgrad operand a tail stores | of e_l (adjoint forward sweep)
 __device__ __forceinline__ void dudf_track(float& tmax, const f32x4 v) {
     tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
-template <int SW, int FL>
+template <int SW, int FL, bool TE = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
-                                          unsigned vo, bool isv, float& tmax) {
+                                          unsigned vo, bool isv, TailTrack& tk) {
     f32x4 out;
     if constexpr (SW == SWEEP_FWD) {
         f32x4 s, c;
@@ -170,7 +171,9 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
         DUDF_ST(a.A, ub, vo, out);
-        DUDF_ST(a.E, ub, vo, o2 * acc);            // e_l = r_l Q_l
+        const f32x4 ev = o2 * acc;                   // e_l = r_l Q_l
+        DUDF_ST(a.E, ub, vo, ev);
+        if constexpr (TE) dudf_track(tk.e, ev);      // (per column: what bounds zbar_l in the fp16x3 adjoint reverse sweep)
     } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
         DUDF_ST(a.Z, ub, vo, out);
@@ -241,7 +244,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         DUDF_ST(a.Z, ub, vo, out);
     }
-    if constexpr (amax_row<SW, FL>() >= 0) dudf_track(tmax, out);
+    if constexpr (amax_row<SW, FL>() >= 0) dudf_track(tk.t, out);
     return out;
 }
 

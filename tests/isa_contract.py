@@ -192,6 +192,9 @@ def analyse_f16(asm_path, width=256):
                 if not in_asm:                       # a compiler wait: retires, never harms
                     fifo = fifo[len(fifo) - n:] if n < len(fifo) else fifo
                     continue
+                if n == 0:
+                    continue                         # drains (tile start, the stream's last two steps; not-taken branches in
+                                                     # the steady state): always safe, and not part of the step sequence
                 young = fifo[len(fifo) - n:] if n else []
                 late = sum(1 for kind, ep in young if kind == "dma" and ep < epoch)
                 # slack: operations older than the N youngest that are NOT old DMA pieces, counted up to the first such piece

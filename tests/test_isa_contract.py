@@ -60,8 +60,9 @@ def test_bf16_sweep_wait_counts(tmp_path, bf16_asm):
         assert set(res) == keys
         for key, v in res.items():
             assert v["scratch"] == 0, (force, key)
-            if force == 1 and key[0] < 4:
+            if force == 1:
                 continue        # the late order belongs to waves 4-7, which issue no DMA pieces and do not wait for any
+                                # (every variant: `dma2` and the hand-written wait sit behind `wave < NWB / 2`)
             for dma, ops, n in v["steps"]:
                 assert n <= 2 * ops + dma, f"late={force} sweep_bf16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) with {ops} ops/step"
             # the unrolled steps of a layer (the first entry also carries the first layer's prologue traffic): waves 0-3 issue
@@ -96,13 +97,16 @@ def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
     for force in (0, 1):
         asm = bf16_asm[f"late{force}"]
         res = analyse_f16(asm)
-        assert (0, 3) in res and (0, 2) in res and (0, 0) in res, sorted(res)
+        assert set(res) == {(0, 3), (0, 2), (0, 0), (1, 1), (1, 0), (2, 0), (3, 1), (3, 0)}, sorted(res)
         for key, v in res.items():
             assert v["scratch"] == 0, (force, key)
             assert len(v["waits"]) >= 8, (force, key, v["waits"])
             for n, late, slack in v["waits"]:
                 assert late == 0, f"late={force} sweep_f16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) leaves {late} pieces of the next chunk in flight"
-            assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
+            # the forward sweep has no operand loads: its hand-written wait is the only one of a step and must not be needlessly
+            # strict (the other sweeps' operand waits, placed by the compiler, retire the older DMA pieces anyway)
+            if key[0] == 0 and force == 0:
+                assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
     txt = open(bf16_asm["ship"]).read()
     names = re.findall(r"^(_ZN\w*sweep_f16_np_kernelILi256ELi\dELi\dE\w*):", txt, re.M)
     assert len(names) >= 3
