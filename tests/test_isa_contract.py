@@ -99,7 +99,6 @@ def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
         res = analyse_f16(asm)
         assert set(res) == {(0, 3), (0, 2), (0, 0), (1, 1), (1, 0), (2, 0), (3, 1), (3, 0)}, sorted(res)
         for key, v in res.items():
-            assert v["scratch"] == 0, (force, key)
             assert len(v["waits"]) >= 8, (force, key, v["waits"])
             for n, late, slack in v["waits"]:
                 assert late == 0, f"late={force} sweep_f16_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) leaves {late} pieces of the next chunk in flight"
@@ -107,6 +106,8 @@ def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
             # strict (the other sweeps' operand waits, placed by the compiler, retire the older DMA pieces anyway)
             if key[0] == 0 and force == 0:
                 assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
+    ship = analyse_f16(bf16_asm["ship"])                # the shipped kernels (both orders behind a wave-uniform branch): no spills
+    assert len(ship) == 8 and all(v["scratch"] == 0 for v in ship.values()), {k: v["scratch"] for k, v in ship.items()}
     txt = open(bf16_asm["ship"]).read()
     names = re.findall(r"^(_ZN\w*sweep_f16_np_kernelILi256ELi\dELi\dE\w*):", txt, re.M)
     assert len(names) >= 3
