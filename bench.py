@@ -7,14 +7,18 @@ already resident in HBM:
     SIREN 8x256 forward + df/dx + hyperbolic-scaled Eikonal/UDF loss (loss_s1, Hessian weight 0)
     + backward to theta + (all-reduce) + Adam.
 Workload at N GPUs: 100 000 points PER GPU (weak scaling), uniform in [-1,1]^3, thirds [on-surface | far | near] like
-the reference sampler.  Arithmetic is fp32 throughout; the hidden-layer matmuls run on the bf16 matrix cores with both
-fp32 operands split exactly into three bf16 pieces (six products, fp32 accumulate: "bf16x6", fp32-equivalent).
+the reference sampler.  Arithmetic is fp32 throughout; the hidden-layer matmuls run on the 16-bit matrix cores with both
+fp32 operands split into two fp16 pieces ("fp16x3": three products, fp32 accumulate; DUDF_SPLIT=bf16: three bf16 pieces,
+six products) — fp32-equivalent, held to the fp32 parity tolerances.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--hidden H] [--no-cpu-baseline] [--no-config3]
 
 Prints ONE JSON line on rank 0.  Timing protocol: W untimed warm-up steps, then EXACTLY K steps between two
-barrier + synchronize pairs with the library's HIP-event profiler OFF; the per-kernel durations behind `roofline` come
-from a SEPARATE, untimed pass of a few steps with the profiler on (events on the launch stream).
+barrier + synchronize pairs with the library's HIP-event profiler OFF; one event per step on the launch stream gives the
+per-step durations, and `value` is the batch size over their MEDIAN (`ms_per_step_mean` is the wall time
+between the barriers / K).  The per-kernel durations behind `roofline` come from a SEPARATE, untimed pass of a few steps
+with the profiler on (events on the launch stream, minus the measured cost of an empty event pair), together with the
+shader clock each kernel ran at (dudf_profile_clocks).
 """
 import argparse
 import ctypes
@@ -138,60 +142,111 @@ class Runner:
         step = lambda: eng.step(hip_ops.LOSS_S1, x, nrm, sdf, weights, ALPHA, lr=1e-4, n_global=n_global, n_hess=n_hess)  # noqa: E731
         for _ in range(warmup):
             step()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         self.barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for i in range(steps):
             terms = step()
+            marks[i + 1].record()                      # one event per step on the launch stream: no host synchronisation
         self.barrier()
         el = time.perf_counter() - t0
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        med = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
         final_loss = float(terms.sum())
-        if self.world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=self.dev)
+        if self.world > 1:                              # the slowest rank sets the pace: MAX of both figures
+            t = torch.tensor([el, med], dtype=torch.float64, device=self.dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t)
-        kern = {}
+            el, med = float(t[0]), float(t[1])
+        info = {"median_ms": med, "min_ms": per_step[0], "max_ms": per_step[-1], "kern": {}, "clocks_mhz": {}, "phases_ms": None,
+                "event_pair_overhead_ms": None, "profiled_step_ms": None, "collectives": getattr(eng, "collectives", None)}
         if profile_steps:
+            # what an empty event pair reads on this stream: subtracted from every per-kernel duration (round 2: the raw
+            # figures summed to more than the step they are part of)
+            pairs = []
+            for _ in range(64):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); b.record(); pairs.append((a, b))
+            torch.cuda.synchronize()
+            ov = sorted(a.elapsed_time(b) for a, b in pairs)[32]
             self.lib.dudf_profile_enable(1)
-            for _ in range(profile_steps):
+            eng.profile = self.world > 1
+            pm = [torch.cuda.Event(enable_timing=True) for _ in range(profile_steps + 1)]
+            pm[0].record()
+            for i in range(profile_steps):
                 step()
+                pm[i + 1].record()
             torch.cuda.synchronize()
             self.lib.dudf_profile_enable(0)
+            eng.profile = False
             buf = ctypes.create_string_buffer(4096)
             self.lib.dudf_profile_dump(buf, len(buf))
             for line in buf.value.decode().splitlines():
                 name, cnt, tot = line.split()
-                kern[name] = float(tot) / int(cnt)
+                info["kern"][name] = max(float(tot) / int(cnt) - ov, 0.0)
+            self.lib.dudf_profile_clocks(buf, len(buf))
+            for line in buf.value.decode().splitlines():
+                name, mhz = line.split()
+                info["clocks_mhz"][name] = float(mhz)
+            info["event_pair_overhead_ms"] = ov
+            info["profiled_step_ms"] = sorted(pm[i].elapsed_time(pm[i + 1]) for i in range(profile_steps))[profile_steps // 2]
+            if self.world > 1:
+                info["phases_ms"] = {k: round(v, 4) for k, v in eng.phase_times().items()}
         del eng
-        return el, kern, final_loss, n_global, n_hess
+        return el, info, final_loss, n_global, n_hess
 
 
-def roofline_block(args, kern, hidden, layers, points, n_hess, ms_step):
+# stash traffic of each kernel in units of one [layer][H][column] fp32 array: (reads, writes, layers)
+STASH_UNITS = {"sweep_fwd": (0, 2, "L"), "sweep_rev": (2, 2, "L"), "sweep_adj_fwd": (2, 2, "L"), "sweep_adj_rev": (2, 1, "L"),
+               "wgrad_hidden": (4, 0, "L-1"), "wgrad_small": (4, 0, "1")}
+SPLIT_BIT = {"sweep_fwd": 0, "sweep_rev": 1, "sweep_adj_fwd": 2, "sweep_adj_rev": 3, "wgrad_hidden": 4}
+
+
+def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
+    """Every MFMA kernel against BOTH ceilings it could be bound by — the matrix pipe (executed MFMA flops = algorithmic
+    flops x products per multiply of its operand split) and HBM (the stash bytes its dataflow moves) — and
+    the `roofline` object of the dominant (longest) kernel, priced on whichever of the two it sits closer to."""
+    from diffudf_amd import _lib, hip_ops
+    kern = info["kern"]
     F0 = f0(hidden, layers)
     hid = 2 * (layers - 1) * hidden * hidden                    # hidden x hidden matmul flops per point
     alg = {"sweep_fwd": F0, "sweep_rev": F0, "sweep_adj_fwd": F0, "sweep_adj_rev": F0,
            "wgrad_hidden": 2 * hid, "wgrad_small": 2 * (F0 - hid)}
-    # which matrix-core instruction a kernel runs on: f32-input MFMA (1 MFMA flop per algorithmic flop, 157.3 TF) or the
-    # 3-way bf16 split at fp32 accuracy (6 bf16 MFMA flops per algorithmic flop, 2.5 PF dense)
-    bf16x6 = {"wgrad_hidden"} if os.environ.get("DUDF_WGRAD", "bf16")[0] != "f" else set()
-    if hidden in (128, 256, 512) and layers >= 2 and os.environ.get("DUDF_SWEEP", "bf16")[0] != "f":
-        from diffudf_amd import hip_ops
-        if hip_ops.sweeps_on_bf16(hidden, layers):
-            bf16x6 |= {"sweep_fwd", "sweep_rev", "sweep_adj_fwd", "sweep_adj_rev"}
+    # which matrix-core path a kernel takes: f32-input MFMA (1 executed flop per algorithmic flop, 157.3 TF), the exact
+    # three-piece bf16 split (6 products, 2.5 PF dense) or the fp16 hi/lo split (3 products, same pipe)
+    on16 = set()
+    if os.environ.get("DUDF_WGRAD", "bf16")[0] != "f":
+        on16.add("wgrad_hidden")
+    if hidden in (128, 256, 512) and layers >= 2 and os.environ.get("DUDF_SWEEP", "bf16")[0] != "f" and hip_ops.sweeps_on_bf16(hidden, layers):
+        on16 |= {"sweep_fwd", "sweep_rev", "sweep_adj_fwd", "sweep_adj_rev"}
+    mode = _lib.load().dudf_split_mode()
+    fp16_ok = {"sweep_fwd": hidden in (128, 256), "sweep_rev": hidden in (128, 256), "sweep_adj_fwd": hidden in (128, 256),
+               "sweep_adj_rev": hidden in (128, 256), "wgrad_hidden": hidden in (256, 512)}
     n_cols = points + 3 * n_hess                                 # columns the MFMA kernels process: 4 per Hessian-path point
+    Lmap = {"L": layers, "L-1": layers - 1, "1": 1}
     per = {}
     for k, fl in alg.items():
-        if k in kern:
-            tf = fl * n_cols / (kern[k] * 1e-3) / 1e12
-            mult, peak = (6, PEAK_BF16_MFMA_TFLOPS) if k in bf16x6 else (1, PEAK_F32_MFMA_TFLOPS)
-            per[k] = {"avg_ms": round(kern[k], 4), "algorithmic_tflops": round(tf, 2), "mfma": "bf16x6" if k in bf16x6 else "f32",
-                      "executed_tflops": round(tf * mult, 2), "peak": peak, "frac": round(tf * mult / peak, 4)}
+        if k not in kern or kern[k] <= 0:
+            continue
+        tf = fl * n_cols / (kern[k] * 1e-3) / 1e12
+        if k in on16:
+            fp16 = bool((mode >> SPLIT_BIT.get(k, 31)) & 1) and fp16_ok.get(k, False) and n_hess == 0
+            name, mult, peak = ("fp16x3", 3, PEAK_BF16_MFMA_TFLOPS) if fp16 else ("bf16x6", 6, PEAK_BF16_MFMA_TFLOPS)
+        else:
+            name, mult, peak = "f32", 1, PEAK_F32_MFMA_TFLOPS
+        rd, wr, lk = STASH_UNITS[k]
+        sbytes = (rd + wr) * Lmap[lk] * hidden * 4 * n_cols
+        tbs = sbytes / (kern[k] * 1e-3) / 1e12
+        per[k] = {"avg_ms": round(kern[k], 4), "algorithmic_tflops": round(tf, 2), "mfma": name,
+                  "executed_tflops": round(tf * mult, 2), "peak": peak, "frac": round(tf * mult / peak, 4),
+                  "stash_bytes_per_launch": sbytes, "stash_tb_s": round(tbs, 2), "hbm_frac": round(tbs / PEAK_HBM_TB_S, 4),
+                  "clock_mhz": info["clocks_mhz"].get(k)}
     if not per:
         return None
     dom = max(per, key=lambda k: per[k]["avg_ms"])
     mfma_ms = sum(kern[k] for k in alg if k in kern)
-    # whole step against the same ceiling: algorithmic flops x the bf16 products executed per flop / wall time of a step
-    mult_step = 6 if "sweep_fwd" in bf16x6 else 1
-    peak_step = PEAK_BF16_MFMA_TFLOPS if mult_step == 6 else PEAK_F32_MFMA_TFLOPS
+    mult_step = {"fp16x3": 3, "bf16x6": 6, "f32": 1}[per.get("sweep_fwd", per[dom])["mfma"]]
+    peak_step = PEAK_F32_MFMA_TFLOPS if mult_step == 1 else PEAK_BF16_MFMA_TFLOPS
     step_tf = 6 * F0 * n_cols / (ms_step * 1e-3) / 1e12
     traffic, step_hbm, source = None, None, None
     prof_json = os.path.join(REPO, "profiles", "hbm_traffic.json")
@@ -210,7 +265,11 @@ def roofline_block(args, kern, hidden, layers, points, n_hess, ms_step):
             if tot:
                 step_hbm = {"bytes_per_step": tot, "bytes_per_point": round(tot / points),
                             "tb_s_over_mfma_kernels": round(tot / (mfma_ms * 1e-3) / 1e12, 2),
-                            "frac_of_8tb_s": round(tot / (mfma_ms * 1e-3) / 1e12 / PEAK_HBM_TB_S, 3)}
+                            "frac_of_8tb_s": round(tot / (mfma_ms * 1e-3) / 1e12 / PEAK_HBM_TB_S, 3),
+                            "input_output_bytes_per_step": 28 * points + 4 * (alg["sweep_fwd"] // 2 + 1),
+                            "note": "the stash (activations and adjoints kept between the four sweeps and the weight-gradient "
+                                    "GEMM) is this dataflow's traffic; the step's inputs and outputs alone are 28 B per point + 4 B "
+                                    "per parameter (SURVEY.md §8(d))"}
             source = {"file": "profiles/hbm_traffic.json", "collected_by": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                       "passes over this bench (tools/pmc_passes.sh, profiles/summarize_pmc.py; FETCH_SIZE x2 per "
                       "MI355X_MICROARCH.md)", "summary": meta.get("summary"), "build": meta.get("build"),
@@ -218,20 +277,30 @@ def roofline_block(args, kern, hidden, layers, points, n_hess, ms_step):
         except Exception:
             traffic = None
     d = per[dom]
-    return {"bound": "mfma", "kernel": dom, "mfma": d["mfma"], "achieved": d["executed_tflops"], "peak": d["peak"],
-            "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic, "traffic_source": source,
-            "algorithmic_flops_per_launch": alg[dom] * n_cols, "algorithmic_tflops": d["algorithmic_tflops"],
-            "note": ("achieved = executed bf16 MFMA flops (6 per algorithmic flop: exact 3-way bf16 split of both fp32 "
-                     "operands, fp32 accumulate) / HIP-event duration of the launch; algorithmic_tflops is the "
-                     "fp32-equivalent rate") if d["mfma"] == "bf16x6" else
-                    "achieved = algorithmic flops / HIP-event duration on the f32-input MFMA",
-            "step_frac": round(step_tf * mult_step / peak_step, 4),
-            "step_algorithmic_tflops": round(step_tf, 2),
-            "step_note": "step_frac = 6 F0 flops per point x points x executed products per flop / ms_per_step / peak of "
-                         "that pipe: the whole step (all kernels, gaps included) against the ceiling of its matmuls",
-            "all_mfma_kernels": per, "step_hbm": step_hbm,
-            "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k not in alg},
-            "kernel_times_from": f"untimed pass of {PROFILE_STEPS} steps with HIP events on the launch stream (dudf_profile_*)"}
+    hbm_bound = d["hbm_frac"] >= d["frac"]
+    out = {"kernel": dom, "mfma": d["mfma"], "clock_mhz": d["clock_mhz"], "traffic": traffic, "traffic_source": source}
+    if hbm_bound:
+        out.update({"bound": "hbm", "achieved": round(d["stash_tb_s"] * 1e3, 1), "peak": PEAK_HBM_TB_S * 1e3, "unit": "GB/s",
+                    "frac": d["hbm_frac"], "algorithmic_bytes_per_launch": d["stash_bytes_per_launch"],
+                    "note": "achieved = the stash bytes this kernel's dataflow moves per launch (DESIGN.md §3.2: reads + writes of "
+                            "[layer][H][column] fp32 arrays) / its launch duration; the same kernel against the matrix pipe: "
+                            f"{d['executed_tflops']} of {d['peak']} TFLOP/s executed ({d['mfma']})"})
+    else:
+        out.update({"bound": "mfma", "achieved": d["executed_tflops"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
+                    "algorithmic_flops_per_launch": alg[dom] * n_cols, "algorithmic_tflops": d["algorithmic_tflops"],
+                    "note": f"achieved = executed MFMA flops ({mult_step if d['mfma'] != 'f32' else 1} products per algorithmic "
+                            f"multiply: {d['mfma']}) / launch duration; algorithmic_tflops is the fp32-equivalent rate"})
+    out.update({"step_frac": round(step_tf * mult_step / peak_step, 4), "step_algorithmic_tflops": round(step_tf, 2),
+                "step_note": "step_frac = 6 F0 flops per point x points x executed products per flop / ms_per_step / peak of "
+                             "that pipe: the whole step (all kernels, gaps included) against the ceiling of its matmuls",
+                "all_mfma_kernels": per, "step_hbm": step_hbm,
+                "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k not in alg},
+                "kernel_times_sum_ms": round(sum(kern.values()), 4), "profiled_step_ms": info["profiled_step_ms"],
+                "event_pair_overhead_ms": info["event_pair_overhead_ms"],
+                "kernel_times_from": f"untimed pass of {PROFILE_STEPS} steps with HIP events on the launch stream (dudf_profile_*), "
+                                     "minus the duration an empty event pair reads on the same stream; clock_mhz = shader clock "
+                                     "over the lifetime of the kernel's first workgroup (s_memtime / s_memrealtime)"})
+    return out
 
 
 def main():
@@ -273,23 +342,24 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
 
     R = Runner(args, world, rank, dev)
-    el, kern, final_loss, n_global, n_hess = R.run(args.hidden, args.layers, args.points, args.steps, args.warmup, args.loss)
+    el, info, final_loss, n_global, n_hess = R.run(args.hidden, args.layers, args.points, args.steps, args.warmup, args.loss)
     config3 = None
     headline = args.loss == "eikonal" and args.hidden == 256 and args.layers == 8 and args.points == 100000
     if headline and not args.no_config3:
         # BASELINE.json configs[2]: SIREN 8x512, 1 M synthetic points sharded over 8 GPUs = 125 000 per GPU (weak scaling
         # at other N).  Reported as a block of its own, never as `value`.
         s3 = max(10, args.steps // 4)
-        el3, kern3, loss3, ng3, _ = R.run(512, 8, 125000, s3, 3, "eikonal")
-        ms3 = el3 / s3 * 1e3
+        el3, info3, loss3, ng3, _ = R.run(512, 8, 125000, s3, 3, "eikonal")
+        ms3 = info3["median_ms"]
         config3 = {"workload": f"SIREN 8x512 (w0=30), Eikonal loss_s1, 125000 synthetic points per GPU (global batch {ng3}; "
                                "BASELINE.json configs[2] at 8 GPUs), same step definition",
-                   "value": ng3 * s3 / el3, "unit": "points/s", "ms_per_step": ms3, "steps": s3, "n_gpus": world,
-                   "final_loss": loss3, "roofline": roofline_block(args, kern3, 512, 8, 125000, 0, ms3) if rank == 0 else None}
+                   "value": ng3 / (ms3 * 1e-3), "unit": "points/s", "ms_per_step": ms3, "ms_per_step_mean": el3 / s3 * 1e3,
+                   "steps": s3, "n_gpus": world, "final_loss": loss3, "phases_ms": info3["phases_ms"],
+                   "roofline": roofline_block(args, info3, 512, 8, 125000, 0, ms3) if rank == 0 else None}
 
     if rank == 0:
-        ms_step = el / args.steps * 1e3
-        value = n_global * args.steps / el
+        ms_step = info["median_ms"]
+        value = n_global / (ms_step * 1e-3)
         weights = W_EIKONAL if args.loss == "eikonal" else [1e4, 1e4, 1e4, 1e3]
         out = {
             # the headline label is BASELINE.json's metric and only applies to its configuration
@@ -297,19 +367,26 @@ def main():
             else f"train points/sec (SIREN fwd+∇x+{'Eikonal loss' if args.loss == 'eikonal' else 'Hessian+full loss_s1'}+bwd), "
                  f"{args.hidden}×{args.layers} net, {args.points} pts [secondary configuration]",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "ms_per_step_mean": el / args.steps * 1e3, "ms_per_step_min": info["min_ms"],
+            "ms_per_step_max": info["max_ms"],
+            "timing_note": "value = global batch / MEDIAN step duration (one HIP event per step on the launch stream, MAX over "
+                           "ranks); ms_per_step_mean = wall time between the two barrier + synchronize pairs / steps",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 arithmetic throughout. The hidden-layer matmuls of the sweeps and the weight-gradient GEMM "
-                          "run on bf16 MFMA with BOTH fp32 operands split exactly into three bf16 pieces (6 products, fp32 "
-                          "accumulate: fp32-equivalent, held to the same parity tolerances as the f32-input MFMA kernels, "
-                          "which DUDF_SWEEP=f32 / DUDF_WGRAD=f32 select); first/last layer, tails, loss and Adam are plain fp32",
+                          "run on the 16-bit matrix cores with BOTH fp32 operands split into two fp16 pieces hi + lo (3 products "
+                          "hi*hi + hi*lo + lo*hi, fp32 accumulate, power-of-two range scaling: 'fp16x3') or, with "
+                          "DUDF_SPLIT=bf16, exactly into three bf16 pieces (6 products): fp32-equivalent, held to the same parity "
+                          "tolerances as the f32-input MFMA kernels, which DUDF_SWEEP=f32 / DUDF_WGRAD=f32 select; first/last "
+                          "layer, tails, loss and Adam are plain fp32",
             "config": {"workload": f"SIREN {args.layers}x{args.hidden} (w0=30), loss_s1 weights {weights} "
                                    f"({'Eikonal-only' if args.loss == 'eikonal' else 'Hessian term on'}), alpha=100, {args.points} "
                                    f"synthetic points per GPU (global batch {n_global}), step = fwd + df/dx + loss + bwd + "
                                    f"{'RCCL all-reduce + ' if world > 1 else ''}Adam",
                        "points_per_gpu": args.points, "global_batch": n_global, "hidden": args.hidden,
                        "layers": args.layers, "parallelism": f"point-batch sharding x{world}, replicated theta"},
-            "roofline": roofline_block(args, kern, args.hidden, args.layers, args.points, n_hess, ms_step),
+            "roofline": roofline_block(args, info, args.hidden, args.layers, args.points, n_hess, ms_step),
+            "phases_ms": info["phases_ms"], "collectives": info["collectives"] if world > 1 else None,
             "final_loss": final_loss,
             "config3": config3,
         }

@@ -77,7 +77,9 @@ SYMBOLS = {
     "dudf_capudf_count": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_double, _P, _P, ctypes.c_size_t, _P]),
     "dudf_capudf_emit": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_double, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "dudf_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "dudf_split_mode": (ctypes.c_int, []),
     "dudf_profile_dump": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "dudf_profile_clocks": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int64, _P, _P, ctypes.c_size_t, _P]),
 }

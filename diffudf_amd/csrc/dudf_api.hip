@@ -14,11 +14,14 @@ std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t g_prof_open[PROF_NSLOTS];
 const char* kProfNames[PROF_NSLOTS] = {"pack", "sweep_fwd", "sweep_rev", "sweep_adj_fwd", "sweep_adj_rev",
                                        "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam", "other"};
+unsigned long long* g_prof_clk = nullptr;               // device: [PROF_NSLOTS][2]
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 }  // namespace
+
+unsigned long long* dudf_prof_clk(int slot) { return (g_prof_on && g_prof_clk) ? g_prof_clk + 2 * slot : nullptr; }
 
 void dudf_prof_begin(int slot, hipStream_t st) {
     if (!g_prof_on) return;
@@ -72,6 +75,7 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.amax = reinterpret_cast<unsigned*>(ws + lo.ws_amax);
     a.ebound = (lo.ws_ebound != lo.ws_amax) ? ws + lo.ws_ebound : nullptr;
     a.split = dudf_split_mask();
+    a.clk = nullptr;
     a.x4 = ws + lo.ws_x4; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;
     a.S = ws + lo.ws_S; a.C = ws + lo.ws_C; a.ZS = ws + lo.ws_ZS; a.Q = ws + lo.ws_Q; a.R = ws + lo.ws_R;
     a.E = ws + lo.ws_E; a.A = ws + lo.ws_A; a.Z = ws + lo.ws_Z;
@@ -185,6 +189,10 @@ extern "C" {
 const char* dudf_version(void) {
     return "dudf_hip 0.3 (gfx950: bf16x6 MFMA sweeps and weight-gradient GEMM at fp32 accuracy, f32-input MFMA variants, "
            "Hessian quads, third-order jets, GPU sampler, ray marching)";
+}
+
+int dudf_split_mode(void) {
+    return dudf_split_mask() | (dudf_split_fp16() ? 16 : 0);
 }
 
 int dudf_sweeps_bf16x6(const dudf_net_cfg* cfg) {
@@ -483,6 +491,27 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
 
 int dudf_profile_enable(int on) {
     g_prof_on = (on != 0);
+    if (g_prof_on && !g_prof_clk) {
+        if (hipMalloc(&g_prof_clk, PROF_NSLOTS * 2 * sizeof(unsigned long long)) != hipSuccess) { g_prof_clk = nullptr; return 0; }
+    }
+    if (g_prof_on && g_prof_clk) (void)hipMemset(g_prof_clk, 0, PROF_NSLOTS * 2 * sizeof(unsigned long long));
+    return 0;
+}
+
+int dudf_profile_clocks(char* buf, size_t buflen) {
+    if (!g_prof_clk) { if (buflen) buf[0] = 0; return 0; }
+    unsigned long long h[PROF_NSLOTS][2];
+    hipError_t e = hipMemcpy(h, g_prof_clk, sizeof(h), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    size_t off = 0;
+    for (int i = 0; i < PROF_NSLOTS; ++i) {
+        if (!h[i][0] || !h[i][1]) continue;
+        // s_memrealtime ticks at the 100 MHz reference clock, s_memtime at the shader clock
+        int w = snprintf(buf + off, off < buflen ? buflen - off : 0, "%s %.1f\n", kProfNames[i], (double)h[i][0] / (double)h[i][1] * 100.0);
+        if (w < 0 || off + (size_t)w >= buflen) return DUDF_E_WORKSPACE;
+        off += (size_t)w;
+    }
+    if (off < buflen) buf[off] = 0;
     return 0;
 }
 

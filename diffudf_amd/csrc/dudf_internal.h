@@ -128,6 +128,7 @@ struct SweepArgs {
     const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l
     unsigned* amax;           // [4][L]: running maxima of |q_l|, |A_l|, |zbar_l|, |h_l| of the quads (bit patterns), or nullptr
     float* ebound;            // [L][np]: per layer and column, max over features of |e_l| (written by SWEEP_ADJ_FWD), or nullptr
+    unsigned long long* clk;  // profiling: [2] shader-clock / 100 MHz reference-clock ticks of workgroup 0's lifetime, or nullptr
     int split;                // bit s: sweep s (SWEEP_FWD .. SWEEP_ADJ_REV) of the plain columns runs the fp16x3 kernel (DUDF_SPLIT)
     const float* x4;          // [np][4]: layer-1 B operand per column
     float* y; float* g;       // [np], [np][4]
@@ -199,6 +200,9 @@ int dudf_split_mask();
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,
        PROF_WGRAD_SMALL, PROF_LOSS_FWD, PROF_LOSS_BWD, PROF_ADAM, PROF_OTHER, PROF_NSLOTS };
+// device slot [2] where the kernel of `slot` leaves (s_memtime, s_memrealtime) deltas of its first workgroup while the
+// profiler is on (nullptr otherwise): the clock the chip actually held under that kernel (dudf_profile_clocks)
+unsigned long long* dudf_prof_clk(int slot);
 void dudf_prof_begin(int slot, hipStream_t st);
 void dudf_prof_end(int slot, hipStream_t st);
 struct DudfProfScope {

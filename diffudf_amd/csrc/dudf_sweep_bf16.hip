@@ -643,6 +643,8 @@ template <int H, int SW, int FL, int SP = 0>
 __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
+    const bool clk_on = a.clk != nullptr && blockIdx.x == 0;   // profiling: the clock this kernel runs at
+    const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     constexpr int kRow = amax_row<SW, FL>();
     unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
     if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }   // (sweep_tile_b starts with a barrier)
@@ -670,6 +672,10 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
             const unsigned v = lds_amax[threadIdx.x];
             if (v) atomicMax(a.amax + kRow * a.L + threadIdx.x, v);
         }
+    }
+    if (clk_on && threadIdx.x == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
 }
 // Two code generations of the same body.  The packed fp32 instructions (v_pk_fma_f32 ...) halve the vector-ALU issue
@@ -1179,8 +1185,10 @@ bool dudf_sweep_bf16_supported(int which, int H, int L) {
     return (H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
 }
 
-int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st) {
+int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a0, hipStream_t st) {
     DudfProfScope prof(PROF_SWEEP_FWD + (which & 3), st);
+    SweepArgs a = a0;
+    a.clk = (which <= SWEEP_ADJ_REV) ? dudf_prof_clk(PROF_SWEEP_FWD + which) : nullptr;   // plain columns only
     switch (H) {
         case 256: return launch_b<256>(which, a, st);
         case 128: return launch_b<128>(which, a, st);

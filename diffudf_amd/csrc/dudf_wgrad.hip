@@ -42,6 +42,7 @@ struct WgradArgs {
     int j0, nj;                         // hidden matrices [j0, j0 + nj) of this launch (matrix j = layer l = j + 2); grid.x = nj
     int Hs;                             // real layer width; the kernels' template H is the output TILE (<= 256):
                                         // blockIdx.z walks the (Hs/H)^2 tiles of a wider layer
+    unsigned long long* clk;            // profiling: (shader clock, 100 MHz reference) ticks of workgroup (0,0,0), or nullptr
     const unsigned* amax;               // [4][L] bit patterns of max |q_l|, |A_l|, |zbar_l| over all columns (fp16x3 kernel)
 };
 
@@ -456,6 +457,8 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     const int tz = a.Hs / H;
     const int o_off = (blockIdx.z / tz) * H, i_off = (blockIdx.z % tz) * H;
     const int64_t xrow = (int64_t)(o_off / 4) * a.np * 4, yrow = (int64_t)(i_off / 4) * a.np * 4;
+    const bool clk_on = a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     f32x16 acc[W::MT][W::NTL];
 #pragma unroll
@@ -833,6 +836,10 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
             red(bacc.x, 0); red(bacc.y, 1); red(bacc.z, 2); red(bacc.w, 3);
         }
     }
+    if (clk_on && tid == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
 }
 // built without packed fp32 instructions (dudf_internal.h, DUDF_NO_PK): the split slices of one wave then execute beside its
 // SIMD partner's MFMAs (-5 % on this kernel).  The body is a forced-inline function: lambdas defined inside a function
@@ -1023,6 +1030,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride; a.steps_total = (int)(lo.ncols / KT); a.L = lo.L;
     a.have_g = have_g; a.Hs = lo.H;
     a.amax = reinterpret_cast<const unsigned*>(ws + lo.ws_amax);
+    a.clk = dudf_prof_clk(PROF_WGRAD_HIDDEN);
     const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
     a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;

@@ -227,9 +227,19 @@ int dudf_sample_batch(const float* tri, int64_t n_tri, const float* pc_pos, cons
  * text line per kernel kind, "<name> <launches> <total_ms>\n", into buf (host), then clears the log. */
 int dudf_profile_enable(int on);
 int dudf_profile_dump(char* buf, size_t buflen);
+/* "<kernel> <MHz>" per line: the shader clock the chip held under each MFMA kernel of the last profiled launches (ratio of
+ * s_memtime to the 100 MHz s_memrealtime over the lifetime of the kernel's first workgroup).  Every roofline fraction
+ * depends on it: the nominal peaks assume 2.4 GHz. */
+int dudf_profile_clocks(char* buf, size_t buflen);
 
 /* library / build identification, host string */
 const char* dudf_version(void);
+/* Which kernels split their fp32 matmul operands into two fp16 pieces (three products, "fp16x3") instead of three bf16
+ * pieces (six products, "bf16x6"): bits 0-3 = the plain columns' forward / reverse / adjoint-forward / adjoint-reverse sweeps,
+ * bit 4 = the weight-gradient GEMM of the 256-wide tiles.  Set by DUDF_SPLIT (bf16 = 0) and DUDF_SPLIT_SWEEPS (A/B testing);
+ * both modes are held to the same fp32 parity tolerances. */
+int dudf_split_mode(void);
+
 /* 1 when the hidden-layer matmuls of this network's plain-column sweeps run on the bf16 matrix cores with the exact
  * 3-way split (bf16x6, fp32-equivalent), 0 when they run on the f32-input MFMA (bench.py prices its roofline with it). */
 int dudf_sweeps_bf16x6(const dudf_net_cfg* cfg);

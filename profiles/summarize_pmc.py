@@ -25,15 +25,20 @@ NAMES = {"<256, 0, 3>": "sweep_fwd", "<256, 1, 1>": "sweep_rev", "<256, 2, 0>": 
 def kname(k):
     if "sweep_bf16_np_kernel" in k:
         k = k.replace("sweep_bf16_np_kernel", "sweep_bf16_kernel")      # the forward sweeps: build without packed fp32 ops
+    for f16 in ("sweep_f16_np_kernel", "sweep_f16_kernel"):             # the fp16x3 builds of the same sweeps (round 3)
+        if f16 in k:
+            k = k.replace(f16, "sweep_bf16_kernel")
     if "sweep_bf16_kernel" in k:
         sig = k.split("sweep_bf16_kernel")[1].split("(")[0]
         return NAMES.get(sig, "sweep" + sig)
     if "sweep_kernel" in k:
         sig = k.split("sweep_kernel")[1].split("(")[0]
         return NAMES.get(sig, "sweep" + sig) + "_f32"
-    for n in ("wgrad_hidden_bf16p", "wgrad_hidden_bf16", "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel", "pack_kernel"):
+    for n in ("wgrad_hidden_f16p", "wgrad_hidden_bf16p", "wgrad_hidden_bf16", "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel",
+              "pack_f16_kernel", "pack_bf16_kernel", "pack_kernel"):
         if n in k:
-            return n.replace("_kernel", "").replace("wgrad_hidden_bf16p", "wgrad_hidden").replace("wgrad_hidden_bf16", "wgrad_hidden")
+            return (n.replace("_kernel", "").replace("wgrad_hidden_f16p", "wgrad_hidden").replace("wgrad_hidden_bf16p", "wgrad_hidden")
+                    .replace("wgrad_hidden_bf16", "wgrad_hidden"))
     return None
 
 
