@@ -40,6 +40,9 @@
 #ifndef DUDF_AD
 #define DUDF_AD 4
 #endif
+#ifndef DUDF_HI_DMA
+#define DUDF_HI_DMA 0                        // partial passes: the idle half issues the DMA pieces (measured: no gain)
+#endif
 #ifndef DUDF_ONESET
 #define DUDF_ONESET 0
 #endif
@@ -336,8 +339,14 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // vector-memory instruction stalls its wave's in-order issue for ~100 cycles when the CU's eight waves contend, and the
     // waves that multiply first (4-7, see `late` below) are the ones the step waits for — their chain loses the six pieces,
     // the other half, which idled at the barrier, takes them (-0.9 % on the step; the reverse assignment: no gain).
+    // A partial pass with at most four active waves (the last pass of a workgroup's share: at 100 000 points a single wave in
+    // 112 workgroups) leaves waves 4-7 idle: they take all the pieces then, the active waves none.
+    const bool hi_dma = DUDF_HI_DMA && nact <= NWB / 2;
     auto dma2 = [&](const char* src, unsigned dst) {
-        if (wave < NWB / 2) { dma_issue<H, SP>(src, dst, voff, wave); dma_issue<H, SP>(src, dst, voff, wave + NWB / 2); }
+        if (hi_dma ? wave >= NWB / 2 : wave < NWB / 2) {
+            const int w = wave & (NWB / 2 - 1);
+            dma_issue<H, SP>(src, dst, voff, w); dma_issue<H, SP>(src, dst, voff, w + NWB / 2);
+        }
     };
     dma2(chunk_src(0), lds0 + gc * G::CHUNKB);
     dma2(chunk_src(1), lds0 + ((gc + 1) % 3) * G::CHUNKB);
@@ -895,19 +904,26 @@ template <> struct WideIn<SWEEP_REV> { static __device__ __forceinline__ const f
 template <> struct WideIn<SWEEP_ADJ_FWD> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.A; } };
 template <> struct WideIn<SWEEP_ADJ_REV> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.Z; } };
 
-struct GeoW {
+template <int SP>
+struct GeoWT {
+    static constexpr int NPC = SP ? 2 : 3;              // pieces per operand (fp16 hi | lo, or bf16 h | m | l)
     static constexpr int H = 512, NT = 32, NKB = 16, FRAG = 1024;
     static constexpr int HALFT = 16;                    // tiles per half-step
-    static constexpr int CHUNKB = HALFT * 3 * FRAG;     // 48 KiB: one (k-block, half) of a matrix
-    static constexpr int IMGB = NKB * 2 * CHUNKB;       // one matrix (= GeoB<512>::IMGB)
-    static constexpr int NDMA = HALFT * 3 / NWB;        // 6 LDS-DMA wave-instructions per wave and chunk
+    static constexpr int CHUNKB = HALFT * NPC * FRAG;   // 48 (32) KiB: one (k-block, half) of a matrix
+    static constexpr int IMGB = NKB * 2 * CHUNKB;       // one matrix (= GeoB<512, SP>::IMGB)
+    static constexpr int NDMA = HALFT * NPC / NWB;      // 6 (4) LDS-DMA wave-instructions per wave and chunk
     static constexpr int NTHR = 64 * NWB;
 };
+using GeoW = GeoWT<0>;
 
-template <int SW, int FL>
+// SP = 1: fp16x3 (see GeoB).  The B operand of a layer is read back from the stash AFTER the whole previous layer has been
+// written, so its per-column scale is exact here: 2^15 over the column's largest |output| of the tail burst.
+template <int SW, int FL, int SP = 0>
 __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
-    using G = GeoW;
+    using G = GeoWT<SP>;
     constexpr int H = G::H;
+    constexpr int NPC = G::NPC;
+    constexpr bool kColScale = SP != 0 && SW != SWEEP_FWD;
     static_assert(SW <= SWEEP_ADJ_REV, "plain columns only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -916,8 +932,11 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     constexpr bool kFwdDir = (SW == SWEEP_FWD || SW == SWEEP_ADJ_FWD);
     const int64_t p = (int64_t)(g_first + wave) * 16 + li;
     auto image = [&](int j) -> const char* {
+        if constexpr (SP) return kFwdDir ? a.wimg16_f + (size_t)j * G::IMGB : a.wimg16_t + (size_t)(nhid - 1 - j) * G::IMGB;
         return kFwdDir ? a.wimg_f + (size_t)j * G::IMGB : a.wimg_t + (size_t)(nhid - 1 - j) * G::IMGB;
     };
+    auto unscale_of = [&](int j) -> float { return a.wsc[kFwdDir ? j : nhid - 1 - j]; };
+    float unscale = 1.f, sb = 1.f, inv_sb = 1.f;        // accumulators -> true values | scale of the B operand being read back
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {
         return layer == 0 ? a.theta + 3 * H : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;
@@ -934,8 +953,8 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         return image(j) + (size_t)(c2 - j * G::NKB * 2) * G::CHUNKB;
     };
     auto dma = [&](int c2, unsigned buf) {
-        // GeoB<256> has the same chunk geometry (16 tiles x 3 pieces, 6 pieces per wave): reuse its issue code
-        dma_issue<256>(chunk_src(c2), (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + buf * G::CHUNKB,
+        // GeoB<256, SP> has the same chunk geometry (16 tiles x NPC pieces): reuse its issue code
+        dma_issue<256, SP>(chunk_src(c2), (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + buf * G::CHUNKB,
                        (unsigned)lane * 16u, wave);
     };
     __syncthreads();                                   // every wave is past its last LDS read of the previous pass
@@ -976,14 +995,18 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             epilogue_loads<SW, FL>(a, stash_base(layer, T), vo, o1[s], o2[s], o3[s]);
             if constexpr (SW == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
         };
+        float cmax = 0.f;                              // fp16x3: largest |output| of this lane's rows of the column
 #pragma unroll
         for (int T = 0; T < PD; ++T) ld(T, T);
 #pragma unroll
         for (int T = 0; T < G::NT; ++T) {
             const int s = T % PD;
             f32x4 z = acc[T];
-            if constexpr (SW == SWEEP_FWD) z += bs[s];
+            if constexpr (SP != 0 && SW == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[s]);
+            else if constexpr (SW == SWEEP_FWD) z += bs[s];
+            else if constexpr (SP != 0) z *= unscale;
             const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, true, tmax);
+            if constexpr (kColScale) dudf_track(cmax, e);
             if (T + PD < G::NT) ld(T + PD, s);
             if (last) {
                 if constexpr (SW == SWEEP_FWD) {
@@ -998,6 +1021,14 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             acc[T] = f32x4{0, 0, 0, 0};
         }
         if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax.t)); }
+        if constexpr (kColScale) {                     // the next layer's B operand = these outputs: scale the column below 2^15
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            unsigned E = (__float_as_uint(cmax) >> 23) & 255u;         // cmax < 2^(E - 126)
+            E = E < 27u ? 27u : (E > 250u ? 250u : E);
+            sb = __uint_as_float((268u - E) << 23);
+            inv_sb = __uint_as_float((E - 14u) << 23);
+        }
     };
     // ---- first layer (fp32, K = 3): pre-activations / incoming adjoints of the 32 tiles, then their tails ----
     {
@@ -1027,9 +1058,10 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %4"
                      : "=&v"(x0), "=&v"(x1) : "v"(vo), "s"(s0), "s"(s1) : "memory");
     };
-    u32x4 bh, bm, bl;
+    u32x4 bq[NPC];                                     // B operand of the current k-block
     for (int j = 0; j < nhid; ++j) {
         const int lin = in_layer(j);
+        if constexpr (SP != 0) unscale = unscale_of(j) * inv_sb;     // what turns THIS matrix's accumulators into true values
         // read-back registers: `xa` carries the even k-blocks, `xb` the odd ones — the loop is unrolled by two so that a set
         // is never copied while its asm loads are in flight (a rolled loop would rotate them with v_mov at the back edge)
         f32x4 xa0, xa1, xb0, xb1;
@@ -1046,37 +1078,53 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
                 if (h == 0) {
                     // the read-back of this k-block was issued one k-block ago; younger than it: the 6 DMA pieces of the
                     // half-step in between
-                    asm volatile("s_waitcnt vmcnt(6)" : "+v"(c0), "+v"(c1));
-                    split8(c0, c1, bh, bm, bl);
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(c0), "+v"(c1) : "n"(G::NDMA));
+                    if constexpr (kColScale) split8h(c0 * sb, c1 * sb, bq[0], bq[1]);
+                    else if constexpr (SP != 0) split8h(c0, c1, bq[0], bq[1]);
+                    else split8(c0, c1, bq[0], bq[1], bq[2]);
                 }
                 if (more) dma(c2 + 2, (gc + 2) % 3);
                 if (h == 0) ld_in(lin, kb + 1 < G::NKB ? kb + 1 : kb, n0, n1);   // the last one re-reads its own: uniform counts
                 __builtin_amdgcn_sched_barrier(0);
                 const char* bp = lds + gc * G::CHUNKB + lane * 16;
-                auto frag = [&](int T, int pc) -> bf16x8 {
-                    return *reinterpret_cast<const bf16x8*>(bp + (T * 3 + pc) * G::FRAG);
+                auto frag = [&](int T, int pc) -> u32x4 {
+                    return *reinterpret_cast<const u32x4*>(bp + (T * NPC + pc) * G::FRAG);
                 };
-                bf16x8 an[2][3] = {{frag(0, 0), frag(0, 1), frag(0, 2)}, {frag(1, 0), frag(1, 1), frag(1, 2)}};
+                u32x4 an[2][NPC];
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) an[T][pc] = frag(T, pc);
 #pragma unroll
                 for (int T = 0; T < G::HALFT; ++T) {
-                    const bf16x8 ah = an[T & 1][0], am = an[T & 1][1], al = an[T & 1][2];
+                    u32x4 af[NPC];
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) af[pc] = an[T & 1][pc];
                     if (T + 2 < G::HALFT) {
-                        an[T & 1][0] = frag(T + 2, 0); an[T & 1][1] = frag(T + 2, 1); an[T & 1][2] = frag(T + 2, 2);
+#pragma unroll
+                        for (int pc = 0; pc < NPC; ++pc) an[T & 1][pc] = frag(T + 2, pc);
                         __builtin_amdgcn_sched_barrier(0x76);
                     }
                     f32x4 cc = acc[G::HALFT * h + T];
-                    cc = mfma_b(am, as_bf(bm), cc);             // smallest terms first
-                    cc = mfma_b(al, as_bf(bh), cc);
-                    cc = mfma_b(ah, as_bf(bl), cc);
-                    cc = mfma_b(am, as_bf(bh), cc);
-                    cc = mfma_b(ah, as_bf(bm), cc);
-                    cc = mfma_b(ah, as_bf(bh), cc);
+                    if constexpr (SP != 0) {                    // smallest terms first: lo*hi, hi*lo, hi*hi
+                        cc = mfma_h(as_h(af[1]), as_h(bq[0]), cc);
+                        cc = mfma_h(as_h(af[0]), as_h(bq[1]), cc);
+                        cc = mfma_h(as_h(af[0]), as_h(bq[0]), cc);
+                    } else {
+                        const bf16x8 ah = as_bf(af[0]), am = as_bf(af[1]), al = as_bf(af[NPC - 1]);
+                        cc = mfma_b(am, as_bf(bq[1]), cc);          // smallest terms first
+                        cc = mfma_b(al, as_bf(bq[0]), cc);
+                        cc = mfma_b(ah, as_bf(bq[NPC - 1]), cc);
+                        cc = mfma_b(am, as_bf(bq[0]), cc);
+                        cc = mfma_b(ah, as_bf(bq[1]), cc);
+                        cc = mfma_b(ah, as_bf(bq[0]), cc);
+                    }
                     acc[G::HALFT * h + T] = cc;
                 }
                 gc = (gc + 1) % 3;
-                // chunk c2+1 has landed.  Issued after its DMA: h == 0: [this step: 6 DMA + 2 read-back]; h == 1: [previous
-                // step: 2 read-back] + [this step: 6 DMA]  ->  8 younger operations either way
-                if (more) dma_wait_b<8>(); else dma_wait_b<0>();
+                // chunk c2+1 has landed.  Issued after its DMA: h == 0: [this step: NDMA pieces + 2 read-back]; h == 1: [previous
+                // step: 2 read-back] + [this step: NDMA pieces]  ->  NDMA + 2 younger operations either way
+                if (more) dma_wait_b<G::NDMA + 2>(); else dma_wait_b<0>();
                 __syncthreads();
             }
         };
@@ -1120,12 +1168,14 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     }
 }
 
-template <int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
+template <int SW, int FL, int SP>
+__device__ __forceinline__ void sweep_w_body(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_w[];
     unsigned gc = 0;
+    const bool clk_on = a.clk != nullptr && blockIdx.x == 0;
+    const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     constexpr int kRow = amax_row<SW, FL>();
-    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_w + 3 * GeoW::CHUNKB);
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_w + 3 * GeoWT<SP>::CHUNKB);
     if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }
     // A/B knob (off by default): odd workgroups start (a.prio >> 8) x 1024 cycles late.  A layer of this kernel is a compute
     // phase (the k-loop, 117 k cycles at 125 k points, matrix pipe 84 % busy) followed by a memory phase (the tail burst,
@@ -1139,7 +1189,7 @@ __global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
-        sweep_tile_w<SW, FL>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_w, gc);
+        sweep_tile_w<SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_w, gc);
     if constexpr (kRow >= 0) {
         __syncthreads();
         if ((int)threadIdx.x < a.L && (int)threadIdx.x < kMaxAmaxLayers && a.amax) {
@@ -1147,7 +1197,15 @@ __global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) {
             if (v) atomicMax(a.amax + kRow * a.L + threadIdx.x, v);
         }
     }
+    if (clk_on && threadIdx.x == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
 }
+template <int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) { sweep_w_body<SW, FL, 0>(a); }
+template <int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_w16_kernel(SweepArgs a) { sweep_w_body<SW, FL, 1>(a); }
 
 int launch_w(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoW;
@@ -1167,6 +1225,28 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
         }                                                                                                   \
         hipLaunchKernelGGL((sweep_w_kernel<SW, FL>), dim3(grid), dim3(G::NTHR), smem, st, a);               \
     } while (0)
+#define DUDF_GO_W16(SW, FL)                                                                                 \
+    do {                                                                                                    \
+        static bool attr_done = false;                                                                      \
+        const size_t smem16 = 3 * GeoWT<1>::CHUNKB + kMaxAmaxLayers * sizeof(unsigned);                     \
+        if (!attr_done) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_w16_kernel<SW, FL>),               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);               \
+            if (e != hipSuccess) return (int)e;                                                             \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((sweep_w16_kernel<SW, FL>), dim3(grid), dim3(G::NTHR), smem16, st, a);           \
+    } while (0)
+    if (which <= SWEEP_ADJ_REV && ((a.split >> which) & 1)) {          // fp16x3 (DUDF_SPLIT, DUDF_SPLIT_SWEEPS)
+        bool done = true;
+        if (which == SWEEP_FWD && a.store_s && a.store_c) DUDF_GO_W16(SWEEP_FWD, 3);
+        else if (which == SWEEP_REV && a.train) DUDF_GO_W16(SWEEP_REV, 1);
+        else if (which == SWEEP_ADJ_FWD) DUDF_GO_W16(SWEEP_ADJ_FWD, 0);
+        else if (which == SWEEP_ADJ_REV) { if (a.have_e) DUDF_GO_W16(SWEEP_ADJ_REV, 1); else DUDF_GO_W16(SWEEP_ADJ_REV, 0); }
+        else done = false;
+        if (done) return (int)hipGetLastError();
+    }
+#undef DUDF_GO_W16
     switch (which) {                                    // training variants only: queries at this width stay on the f32 kernel
         case SWEEP_FWD: if (a.store_s && a.store_c) DUDF_GO_W(SWEEP_FWD, 3); else return DUDF_E_UNSUPPORTED; break;
         case SWEEP_REV: if (a.train) DUDF_GO_W(SWEEP_REV, 1); else return DUDF_E_UNSUPPORTED; break;
