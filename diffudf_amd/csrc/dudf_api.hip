@@ -137,14 +137,24 @@ int open_ctx(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, void* workspace, s
 // one the register allocator handles without spills), queries merely skip the reverse sweep's stores.
 int forward_common(Ctx& c, const float* theta, const float* x, int train, bool reverse) {
     int rc;
-    if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
-    if (use_bf16_sweeps() && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
-    if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
-    SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
-    if (train && dudf_split_fp16()) {                   // running maxima of q_l | A_l | zbar_l (fp16x3 weight-gradient GEMM)
-        hipError_t e = hipMemsetAsync(c.ws + c.lo.ws_amax, 0, (size_t)4 * c.lo.L * sizeof(unsigned), c.st);
+    // One launch: A-operand forms of theta, x4, zeros for the loss sums / ticket and the running maxima.  The bf16x3 images
+    // and W^T are packed only when a kernel that reads them can run: everything except a training step of plain columns
+    // whose four sweeps are all fp16x3 (Hessian quads, jets, A/B modes, very deep nets: bf16x6; f32-input kernels: W^T).
+    const DudfLayout& lo = c.lo;
+    const bool all16 = train && lo.ncol_h == 0 && use_bf16_sweeps() && dudf_split_mask() == 15 && lo.L <= 32;
+    const int need = (all16 ? 0 : 1) | ((!use_bf16_sweeps() || (lo.H == 512 && (lo.ncol_h > 0 || !train))) ? 2 : 0);
+    rc = (lo.L >= 2) ? dudf_launch_prep(lo, theta, x, c.ws, need, c.st) : DUDF_E_UNSUPPORTED;
+    if (rc == DUDF_E_UNSUPPORTED) {                     // widths without 16-bit weight images: the separate kernels
+        if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
+        if (use_bf16_sweeps() && (rc = dudf_launch_pack_bf16(c.lo, theta, c.ws, c.st))) return rc;
+        if (x && (rc = dudf_launch_make_x4(c.lo, x, c.ws, c.st))) return rc;
+        hipError_t e = hipMemsetAsync(c.ws + c.lo.ws_acc, 0, (size_t)2 * DUDF_NACC * sizeof(float), c.st);
+        if (e == hipSuccess) e = hipMemsetAsync(c.ws + c.lo.ws_amax, 0, (size_t)4 * c.lo.L * sizeof(unsigned), c.st);
         if (e != hipSuccess) return (int)e;
+    } else if (rc) {
+        return rc;
     }
+    SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     // what the forward sweep has to leave behind: h_l only for training (weight gradients, r_l), cos if any later sweep
     // runs — a value-only query stores nothing, a value+gradient query half of what training does
     a.store_s = train ? 1 : 0; a.store_c = (reverse || train) ? 1 : 0; a.train = train;
@@ -154,23 +164,24 @@ int forward_common(Ctx& c, const float* theta, const float* x, int train, bool r
 }
 
 // the adjoint sweeps; the weight gradients follow (all layers at once, or layer ranges through dudf_weight_gradient)
-int backward_sweeps(Ctx& c, const float* theta, int have_g);
+int backward_sweeps(Ctx& c, const float* theta, int have_g, bool zeroed = false);
 
-int backward_common(Ctx& c, const float* theta, int have_g, float* dtheta, int accumulate) {
+// `zeroed`: the caller's cotangent kernel (loss_bwd) already cleared d(theta) and the running maxima on its way
+int backward_common(Ctx& c, const float* theta, int have_g, float* dtheta, int accumulate, bool zeroed = false) {
     int rc;
-    if (!accumulate) {
+    if (!accumulate && !zeroed) {
         hipError_t e = hipMemsetAsync(dtheta, 0, (size_t)c.lo.n_theta * sizeof(float), c.st);
         if (e != hipSuccess) return (int)e;
     }
-    if ((rc = backward_sweeps(c, theta, have_g))) return rc;
+    if ((rc = backward_sweeps(c, theta, have_g, zeroed))) return rc;
     return dudf_launch_wgrad(c.lo, c.ws, dtheta, have_g, c.st);
 }
 
-int backward_sweeps(Ctx& c, const float* theta, int have_g) {
+int backward_sweeps(Ctx& c, const float* theta, int have_g, bool zeroed) {
     int rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     a.train = 1;
-    if (dudf_split_fp16()) {                            // a backward may run several times per forward: A_l and zbar_l start over
+    if (dudf_split_fp16() && !(zeroed && 2 * c.lo.L <= 256)) {   // a backward may run several times per forward: A_l and zbar_l start over
         hipError_t e = hipMemsetAsync(c.ws + c.lo.ws_amax + c.lo.L, 0, (size_t)2 * c.lo.L * sizeof(unsigned), c.st);
         if (e != hipSuccess) return (int)e;
     }
@@ -417,9 +428,10 @@ int dudf_loss_backward(const dudf_net_cfg* cfg, int mode, const float* theta, co
     int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
     (void)x;
-    if ((rc = dudf_launch_loss_bwd(c.lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, c.ws, c.st)))
+    if ((rc = dudf_launch_loss_bwd(c.lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, c.ws, c.st,
+                                   accumulate ? nullptr : dtheta, c.lo.n_theta)))
         return rc;
-    return backward_common(c, theta, mode != DUDF_LOSS_S2, dtheta, accumulate);
+    return backward_common(c, theta, mode != DUDF_LOSS_S2, dtheta, accumulate, true);
 }
 
 int dudf_loss_backward_sweeps(const dudf_net_cfg* cfg, int mode, const float* theta, const float* normals, const float* sdf,
@@ -432,7 +444,7 @@ int dudf_loss_backward_sweeps(const dudf_net_cfg* cfg, int mode, const float* th
     int rc = open_ctx(cfg, n_local, n_hess, workspace, workspace_bytes, stream, &c);
     if (rc) return rc;
     if ((rc = dudf_launch_loss_bwd(c.lo, mode, normals, sdf, n_global, weights, alpha, cot, stats, c.ws, c.st))) return rc;
-    return backward_sweeps(c, theta, mode != DUDF_LOSS_S2);
+    return backward_sweeps(c, theta, mode != DUDF_LOSS_S2, true);
 }
 
 int dudf_weight_gradient(const dudf_net_cfg* cfg, int64_t n_local, int64_t n_hess, int have_gradient_terms, int layer_begin,

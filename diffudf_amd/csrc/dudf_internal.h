@@ -163,9 +163,14 @@ int dudf_launch_field_features(const DudfLayout& lo, const float* ws, int invers
                                float* out_vec, int* out_flag_count, float* out_lam, float* out_V, hipStream_t st);
 int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, float* ws, float* out_terms, hipStream_t st);
+// zero_f / zero_fn: a buffer the kernel zeroes on its way (d(theta) in front of the weight-gradient atomics), or nullptr
 int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, const float* cot, const double* stats, float* ws,
-                         hipStream_t st);
+                         hipStream_t st, float* zero_f = nullptr, int64_t zero_fn = 0);
+// ONE launch in front of a training forward: A-operand forms of theta (thin layers, fp16 hi/lo images + their scales;
+// bf16x3 images and W^T only when a kernel that reads them will run), x4 from the points, and zeros for the loss sums and
+// the running maxima.  need: bit 0 = bf16x3 images, bit 1 = W_l^T (f32-input reverse sweeps)
+int dudf_launch_prep(const DudfLayout& lo, const float* theta, const float* x, float* ws, int need, hipStream_t st);
 int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, double* stats, hipStream_t st);
 int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms, hipStream_t st);
 int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,

@@ -52,10 +52,15 @@ struct LossArgs {
     float *ybar, *gbar;                      // per column
     const float* cot;                        // device, 4 floats
     const double* stats;                     // device, 3 doubles (s2)
-    double* acc;                             // device, >= 4 doubles
+    double* acc;                             // device, >= 4 doubles (+ one ticket word behind them)
     int64_t n, n_h, ncol_h, np, ncols;
     float w[4];
     float alpha, inv_n;                      // 1 / n_global
+    // loss_fwd: the last block to finish turns the four sums into the four weighted terms (no second launch)
+    float* out_terms; double wd[4]; double inv_nd;
+    // loss_bwd: buffers this kernel zeroes on its way (d(theta) before the weight-gradient atomics, the running maxima of
+    // A_l / zbar_l before the adjoint sweeps) instead of two memset launches
+    float* zero_f; int64_t zero_fn; unsigned* zero_u; int zero_un;
 };
 
 __device__ __forceinline__ int64_t col_of(const LossArgs& a, int64_t p) {
@@ -198,6 +203,19 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
         }
     }
     block_accumulate<4>(v, a.acc);
+    // last block done: finalize.  (The atomics above are device-scope; the fence orders them before the ticket.)
+    __shared__ bool last;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.acc + 4);
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 4) {
+        __threadfence();
+        const double sum = atomicAdd(a.acc + threadIdx.x, 0.0);       // read through the atomic path: every block's add is visible
+        a.out_terms[threadIdx.x] = (float)(sum * a.inv_nd * a.wd[threadIdx.x]);
+    }
 }
 
 __global__ void loss_finalize_kernel(const double* acc, float* out, double w0, double w1, double w2, double w3,
@@ -223,6 +241,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
         mu = a.stats[1] / cnt;
         sd = sqrt((a.stats[2] - cnt * mu * mu) / (cnt - 1.0));
     }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.zero_fn; i += (int64_t)gridDim.x * blockDim.x) a.zero_f[i] = 0.f;
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.zero_un) a.zero_u[threadIdx.x] = 0u;
     const int64_t nq = a.ncol_h / 4;                                   // quads (padded)
     const int64_t units = nq + (a.ncols - a.ncol_h);
     for (int64_t uidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; uidx < units;
@@ -595,6 +615,8 @@ LossArgs make_loss_args(const DudfLayout& lo, const float* normals, const float*
     a.n = lo.n; a.n_h = lo.n_h; a.ncol_h = lo.ncol_h; a.np = lo.np; a.ncols = lo.ncols;
     for (int i = 0; i < 4; ++i) a.w[i] = (float)w[i];
     a.alpha = (float)alpha; a.inv_n = (float)(1.0 / (double)n_global);
+    a.out_terms = nullptr; a.inv_nd = 0.0; a.wd[0] = a.wd[1] = a.wd[2] = a.wd[3] = 0.0;
+    a.zero_f = nullptr; a.zero_fn = 0; a.zero_u = nullptr; a.zero_un = 0;
     return a;
 }
 
@@ -613,23 +635,25 @@ int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, c
                          const double* w, double alpha, float* ws, float* out_terms, hipStream_t st) {
     DudfProfScope prof(PROF_LOSS_FWD, st);
     LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
-    hipError_t e = hipMemsetAsync(a.acc, 0, 4 * sizeof(double), st);
-    if (e != hipSuccess) return (int)e;
+    // (the four sums and the ticket behind them were zeroed by the forward's prep kernel, dudf_launch_prep)
+    a.out_terms = out_terms; a.inv_nd = 1.0 / (double)n_global;
+    for (int i = 0; i < 4; ++i) a.wd[i] = w[i];
     const int grid = dudf_deterministic() ? 1 : grid_for(lo.n);        // one block: one fixed summation order
     if (mode == DUDF_LOSS_S1) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_S1>, dim3(grid), dim3(256), 0, st, a);
     else if (mode == DUDF_LOSS_SIREN) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_SIREN>, dim3(grid), dim3(256), 0, st, a);
     else return DUDF_E_BADMODE;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a.acc, out_terms, w[0], w[1], w[2], w[3],
-                       1.0 / (double)n_global);
     return (int)hipGetLastError();
 }
 
 int dudf_launch_loss_bwd(const DudfLayout& lo, int mode, const float* normals, const float* sdf, int64_t n_global,
                          const double* w, double alpha, const float* cot, const double* stats, float* ws,
-                         hipStream_t st) {
+                         hipStream_t st, float* zero_f, int64_t zero_fn) {
     DudfProfScope prof(PROF_LOSS_BWD, st);
     LossArgs a = make_loss_args(lo, normals, sdf, n_global, w, alpha, ws);
     a.cot = cot; a.stats = stats;
+    a.zero_f = zero_f; a.zero_fn = zero_f ? zero_fn : 0;
+    // a backward may run several times per forward: the running maxima of A_l and zbar_l (rows 1, 2 of amax) start over
+    a.zero_u = reinterpret_cast<unsigned*>(ws + lo.ws_amax) + lo.L; a.zero_un = (dudf_split_fp16() && 2 * lo.L <= 256) ? 2 * lo.L : 0;
     const int grid = grid_for(lo.np);
     if (mode == DUDF_LOSS_S1) hipLaunchKernelGGL(loss_bwd_kernel<DUDF_LOSS_S1>, dim3(grid), dim3(256), 0, st, a);
     else if (mode == DUDF_LOSS_SIREN) hipLaunchKernelGGL(loss_bwd_kernel<DUDF_LOSS_SIREN>, dim3(grid), dim3(256), 0, st, a);

@@ -706,12 +706,12 @@ __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(Sweep
 
 // theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L
 template <int H>
-__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ theta, char* __restrict__ img_f,
-                                                        char* __restrict__ img_t, int nhid, int64_t off_hid,
-                                                        int64_t hid_stride) {
+__device__ __forceinline__ void pack_bf16_body(const float* __restrict__ theta, char* __restrict__ img_f,
+                                               char* __restrict__ img_t, int nhid, int64_t off_hid,
+                                               int64_t hid_stride, int64_t block, int64_t nblocks) {
     using G = GeoB<H>;
     const int64_t total = (int64_t)2 * nhid * G::NKB * G::NT * 64;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = block * 256 + threadIdx.x; idx < total; idx += nblocks * 256) {
         int64_t v = idx;
         const int lane = (int)(v & 63); v >>= 6;
         const int T = (int)(v % G::NT); v /= G::NT;
@@ -736,16 +736,21 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
         *reinterpret_cast<u32x4*>(base + 2 * G::FRAG) = l;
     }
 }
+template <int H>
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ theta, char* __restrict__ img_f,
+                                                        char* __restrict__ img_t, int nhid, int64_t off_hid,
+                                                        int64_t hid_stride) {
+    pack_bf16_body<H>(theta, img_f, img_t, nhid, off_hid, hid_stride, blockIdx.x, gridDim.x);
+}
 
 // theta -> fp16 hi/lo images of 2^k_j W_l and 2^k_j W_l^T in the same A-fragment order, k_j = 15 - (exponent of max |W_l|):
 // the largest weight lands in [2^14, 2^15), weights down to 2^-18 of it keep two full pieces, smaller ones an absolute
 // error of 2^-40 of the largest.  grid = (blocks per matrix, L - 1); every block reduces max |W_l| itself (256 KB from L2).
 template <int H>
-__global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__ theta, char* __restrict__ img_f,
-                                                       char* __restrict__ img_t, float* __restrict__ wsc, int nhid,
-                                                       int64_t off_hid, int64_t hid_stride) {
+__device__ __forceinline__ void pack_f16_body(const float* __restrict__ theta, char* __restrict__ img_f,
+                                              char* __restrict__ img_t, float* __restrict__ wsc, int nhid,
+                                              int64_t off_hid, int64_t hid_stride, int j, int sub, int nsub) {
     using G = GeoB<H, 1>;
-    const int j = blockIdx.y;
     const float* W = theta + off_hid + (int64_t)j * hid_stride;
     __shared__ float red[4];
     float mx = 0.f;
@@ -762,9 +767,9 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__
     (void)frexpf(mx, &ex);                              // mx < 2^ex (0 -> 0; inf / nan: whatever, the step is lost anyway)
     ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
     const float sc = ldexpf(1.f, 15 - ex);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { wsc[j] = ldexpf(1.f, ex - 15); wsc[nhid + j] = sc; }
+    if (sub == 0 && threadIdx.x == 0) { wsc[j] = ldexpf(1.f, ex - 15); wsc[nhid + j] = sc; }
     const int per = 2 * G::NKB * G::NT * 64;            // lane-items of this matrix: [dir][k-block][tile][lane]
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < per; idx += gridDim.x * 256) {
+    for (int idx = sub * 256 + threadIdx.x; idx < per; idx += nsub * 256) {
         int v = idx;
         const int lane = v & 63; v >>= 6;
         const int T = v % G::NT; v /= G::NT;
@@ -784,6 +789,75 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__
         char* base = (dir == 0 ? img_f : img_t) + (size_t)j * G::IMGB + (size_t)kb * G::CHUNKB + (size_t)T * 2 * G::FRAG + lane * 16;
         *reinterpret_cast<u32x4*>(base) = h;
         *reinterpret_cast<u32x4*>(base + G::FRAG) = l;
+    }
+}
+template <int H>
+__global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__ theta, char* __restrict__ img_f,
+                                                       char* __restrict__ img_t, float* __restrict__ wsc, int nhid,
+                                                       int64_t off_hid, int64_t hid_stride) {
+    pack_f16_body<H>(theta, img_f, img_t, wsc, nhid, off_hid, hid_stride, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// ---- everything a training forward needs in front of its sweeps, in ONE launch (the C ABI keeps its entry points; round 2
+// launched pack, pack_bf16, x4 and two memsets separately: ~5 us each, 1.7 % of a 3.5 ms step).  Block roles by index range.
+struct PrepArgs {
+    const float* theta; const float* x;
+    float *w1b, *w1t16, *wt, *x4, *wsc;
+    char *img16_f, *img16_t, *img_f, *img_t;
+    unsigned* zero; int nzero;                          // the loss sums + ticket and the running maxima: nzero dwords from `zero`
+    unsigned* zero2; int nzero2;
+    int L, nsub;
+    int64_t off_hid, hid_stride, n, n_h, ncol_h, np;
+    int nb_f16, nb_bf16, nb_x4, nb_thin, nb_wt;         // blocks per role
+};
+template <int H>
+__global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
+    int b = blockIdx.x;
+    const int nhid = a.L - 1;
+    if (b < a.nb_f16) { pack_f16_body<H>(a.theta, a.img16_f, a.img16_t, a.wsc, nhid, a.off_hid, a.hid_stride, b / a.nsub, b % a.nsub, a.nsub); return; }
+    b -= a.nb_f16;
+    if (b < a.nb_bf16) { pack_bf16_body<H>(a.theta, a.img_f, a.img_t, nhid, a.off_hid, a.hid_stride, b, a.nb_bf16); return; }
+    b -= a.nb_bf16;
+    if (b < a.nb_x4) {
+        // x4: the layer-1 B operand of every column.  plain column: (x0,x1,x2,1); Hessian quad: channel 0 the same, channel
+        // 1+k = (e_k, 0); padding: zeros (as make_x4_kernel, dudf_misc.hip)
+        for (int64_t c = (int64_t)b * 256 + threadIdx.x; c < a.np; c += (int64_t)a.nb_x4 * 256) {
+            f32x4 v = {0, 0, 0, 0};
+            if (c < a.ncol_h) {
+                const int64_t p = c >> 2; const int ch = (int)(c & 3);
+                if (p < a.n_h) {
+                    if (ch == 0) v = f32x4{a.x[p * 3], a.x[p * 3 + 1], a.x[p * 3 + 2], 1.f};
+                    else v[ch - 1] = 1.f;
+                }
+            } else {
+                const int64_t p = a.n_h + (c - a.ncol_h);
+                if (p < a.n) v = f32x4{a.x[p * 3], a.x[p * 3 + 1], a.x[p * 3 + 2], 1.f};
+            }
+            *reinterpret_cast<f32x4*>(a.x4 + c * 4) = v;
+        }
+        return;
+    }
+    b -= a.nb_x4;
+    if (b < a.nb_thin) {                                 // w1b[f][k] = k<3 ? W_1[f][k] : b_1[f];  w1t16[r][f] = r<3 ? W_1[f][r] : 0;  zeros
+        for (int gid = b * 256 + threadIdx.x; gid < 16 * H; gid += a.nb_thin * 256) {
+            if (gid < 4 * H) { const int f = gid / 4, k = gid % 4; a.w1b[gid] = k < 3 ? a.theta[f * 3 + k] : a.theta[3 * H + f]; }
+            const int r = gid / H, f = gid % H;
+            a.w1t16[gid] = r < 3 ? a.theta[f * 3 + r] : 0.f;
+        }
+        if (b == 0) {
+            for (int i = threadIdx.x; i < a.nzero; i += 256) a.zero[i] = 0u;
+            for (int i = threadIdx.x; i < a.nzero2; i += 256) a.zero2[i] = 0u;
+        }
+        return;
+    }
+    b -= a.nb_thin;
+    {                                                    // wt[j][i][o] = W_{j+2}[o][i] (f32-input reverse sweeps)
+        const int64_t n_wt = (int64_t)nhid * H * H;
+        for (int64_t gid = (int64_t)b * 256 + threadIdx.x; gid < n_wt; gid += (int64_t)a.nb_wt * 256) {
+            const int64_t j = gid / ((int64_t)H * H), rem = gid % ((int64_t)H * H);
+            const int i = (int)(rem / H), o = (int)(rem % H);
+            a.wt[gid] = a.theta[a.off_hid + j * a.hid_stride + (int64_t)o * H + i];
+        }
     }
 }
 
@@ -1296,6 +1370,40 @@ int pack_b(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) 
     return (int)hipGetLastError();
 }
 }  // namespace
+
+namespace {
+template <int H>
+int prep_b(const DudfLayout& lo, const float* theta, const float* x, float* ws, int need, hipStream_t st) {
+    PrepArgs a;
+    a.theta = theta; a.x = x;
+    a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt; a.x4 = ws + lo.ws_x4; a.wsc = ws + lo.ws_wsc;
+    a.img_f = reinterpret_cast<char*>(ws + lo.ws_wimg); a.img_t = a.img_f + (size_t)(lo.L - 1) * GeoB<H>::IMGB;
+    a.img16_f = reinterpret_cast<char*>(ws + lo.ws_wimg16); a.img16_t = a.img16_f + (size_t)(lo.L - 1) * GeoB<H, 1>::IMGB;
+    a.zero = reinterpret_cast<unsigned*>(ws + lo.ws_acc); a.nzero = 2 * DUDF_NACC;
+    a.zero2 = reinterpret_cast<unsigned*>(ws + lo.ws_amax); a.nzero2 = 4 * lo.L;
+    a.L = lo.L; a.off_hid = lo.off_hid; a.hid_stride = lo.hid_stride;
+    a.n = lo.n; a.n_h = lo.n_h; a.ncol_h = lo.ncol_h; a.np = lo.np;
+    const int nhid = lo.L - 1;
+    a.nsub = H >= 256 ? 16 : 4;
+    a.nb_f16 = (dudf_split_fp16() && nhid > 0) ? nhid * a.nsub : 0;
+    a.nb_bf16 = ((need & 1) && nhid > 0) ? (int)(((int64_t)2 * nhid * GeoB<H>::NKB * GeoB<H>::NT * 64 + 255) / 256) : 0;
+    a.nb_x4 = x ? (int)((lo.np + 255) / 256 < 1024 ? (lo.np + 255) / 256 : 1024) : 0;
+    a.nb_thin = 2;
+    a.nb_wt = ((need & 2) && nhid > 0) ? (int)(((int64_t)nhid * H * H + 255) / 256 < 2048 ? ((int64_t)nhid * H * H + 255) / 256 : 2048) : 0;
+    const int grid = a.nb_f16 + a.nb_bf16 + a.nb_x4 + a.nb_thin + a.nb_wt;
+    hipLaunchKernelGGL(prep_kernel<H>, dim3(grid), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+// Returns DUDF_E_UNSUPPORTED for widths without 16-bit weight images (the caller then packs with the separate kernels).
+int dudf_launch_prep(const DudfLayout& lo, const float* theta, const float* x, float* ws, int need, hipStream_t st) {
+    DudfProfScope prof(PROF_PACK, st);
+    if (lo.H == 256) return prep_b<256>(lo, theta, x, ws, need, st);
+    if (lo.H == 128) return prep_b<128>(lo, theta, x, ws, need, st);
+    if (lo.H == 512) return prep_b<512>(lo, theta, x, ws, need, st);
+    return DUDF_E_UNSUPPORTED;
+}
 
 int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st) {
     if (lo.L < 2) return 0;
