@@ -12,12 +12,29 @@ from . import _lib
 from ._lib import NetCfg, LOSS_S1, LOSS_S2, LOSS_SIREN  # noqa: F401
 
 
+BUILT_WIDTHS = (32, 64, 128, 256, 512)               # hidden widths the kernels are built for
+
+
+def padded_width(hidden):
+    """The built width a `hidden_layer_config` runs at: the smallest one >= its widest layer.  Zero-padding a sine MLP is
+    exact: a padded unit has a zero weight row and bias (z = 0, sin = 0), the next layer's columns that read it are zero, so
+    nothing it touches — value, df/dx, Hessian, any parameter gradient — changes (reference src/model.py:94-108 builds any
+    list of widths; `diffudf_amd.model.SIREN` keeps the caller's shapes as strided views of the padded buffer)."""
+    hidden = [int(h) for h in hidden]
+    if not hidden or min(hidden) < 1:
+        raise _lib.DudfError(f"hidden_layer_config must name at least one positive width; got {hidden}")
+    if max(hidden) > BUILT_WIDTHS[-1]:
+        raise _lib.DudfError(f"widest built layer is {BUILT_WIDTHS[-1]}; got hidden_layer_config={hidden}")
+    return min(b for b in BUILT_WIDTHS if b >= max(hidden))
+
+
 def make_cfg(hidden, w0=30.0, n_in=3, n_out=1):
+    """C-ABI network descriptor of SIREN(3, 1, hidden): L = len(hidden) layers of the padded width."""
     hidden = list(hidden)
-    if n_in != 3 or n_out != 1 or len(hidden) < 1 or any(h != hidden[0] for h in hidden):
-        raise _lib.DudfError("HIP path supports SIREN(3, 1, [H]*L) with equal hidden widths; got "
+    if n_in != 3 or n_out != 1 or len(hidden) < 1:
+        raise _lib.DudfError("HIP path supports SIREN(3, 1, [...]) (3-D points, scalar field); got "
                              f"n_in={n_in}, n_out={n_out}, hidden={hidden}")
-    return NetCfg(3, len(hidden), int(hidden[0]), float(w0))
+    return NetCfg(3, len(hidden), padded_width(hidden), float(w0))
 
 
 def sweeps_on_bf16(hidden, layers, w0=30.0):

@@ -14,6 +14,10 @@ What is kept from the reference interface
 What is different inside
   * all 18 parameters are views into ONE flat fp32 buffer in state_dict order — the `theta` the C ABI takes;
     `torch.optim.Adam(model.parameters())` updates it in place exactly as it updates the reference's tensors
+  * ANY `hidden_layer_config` runs (reference src/model.py:94-108): the buffer has the layout of SIREN(3, 1, [Hp]*L) with
+    Hp the smallest built width >= the widest layer, zero outside the caller's shapes (exact for a sine MLP, see
+    hip_ops.padded_width); the parameters are strided views of it with the CALLER's shapes, so state_dict, optimizers and
+    autograd never see a padded entry
   * `forward` runs the fused HIP value sweep; there is no PyTorch/CPU fallback: CPU inputs raise.
 """
 import math
@@ -98,30 +102,56 @@ class SIREN(nn.Module):
     def _linears(self):
         return [blk[0] for blk in self.net]
 
+    def _padded_dims(self):
+        """[(rows, cols)] of every layer's weight in the C-ABI layout: SIREN(n_in, n_out, [Hp]*L)."""
+        L = len(self.hidden_layer_config)
+        if L == 0:
+            return [(self.n_out_features, self.n_in_features)]
+        try:
+            hp = hip_ops.padded_width(self.hidden_layer_config)
+        except DudfError:                                 # no HIP path for this network (hip_cfg raises when it is used)
+            hp = None
+        dims = []
+        for i, l in enumerate(self._linears()):
+            o, k = l.weight.shape
+            dims.append((o if (hp is None or i == L) else hp, k if (hp is None or i == 0) else hp))
+        return dims
+
+    def _views_of(self, flat):
+        """Per-parameter views (the caller's shapes; strided where the layer is narrower than the padded width) of a
+        buffer in the C-ABI layout, in `parameters()` order."""
+        out, off = [], 0
+        for l, (po, pk) in zip(self._linears(), self._padded_dims()):
+            o, k = l.weight.shape
+            out.append(flat[off:off + po * pk].view(po, pk)[:o, :k])
+            off += po * pk
+            out.append(flat[off:off + po][:o])
+            off += po
+        return out
+
+    def _flat_numel(self):
+        return sum(po * pk + po for po, pk in self._padded_dims())
+
     def _flatten(self):
-        """(Re)build the flat buffer and point every parameter at its slice of it."""
+        """(Re)build the flat buffer and point every parameter at its (strided) view of it."""
         lins = self._linears()
         with torch.no_grad():
-            flat = torch.cat([torch.cat([l.weight.detach().reshape(-1), l.bias.detach().reshape(-1)]) for l in lins])
-            flat = flat.contiguous().clone()
-            off = 0
-            for l in lins:
-                for p in (l.weight, l.bias):
-                    n = p.numel()
-                    p.data = flat[off:off + n].view(p.shape)
-                    off += n
+            ref = lins[0].weight
+            flat = torch.zeros(self._flat_numel(), dtype=ref.dtype, device=ref.device)
+            params = [p for l in lins for p in (l.weight, l.bias)]
+            for p, v in zip(params, self._views_of(flat)):
+                v.copy_(p.detach())
+                p.data = v
         self._flat = flat
 
     def _is_flat(self):
         if self._flat is None:
             return False
-        off = self._flat.data_ptr()
-        es = self._flat.element_size()
-        for l in self._linears():
-            for p in (l.weight, l.bias):
-                if p.data_ptr() != off or p.dtype != self._flat.dtype or p.device != self._flat.device:
-                    return False
-                off += p.numel() * es
+        params = [p for l in self._linears() for p in (l.weight, l.bias)]
+        for p, v in zip(params, self._views_of(self._flat)):
+            if (p.data_ptr() != v.data_ptr() or p.stride() != v.stride() or p.dtype != self._flat.dtype
+                    or p.device != self._flat.device):
+                return False
         return True
 
     def _apply(self, fn, *args, **kwargs):
@@ -143,13 +173,7 @@ class SIREN(nn.Module):
 
     def split_flat(self, flat):
         """Views of a theta-shaped tensor, one per parameter, in `parameters()` order."""
-        out, off = [], 0
-        for l in self._linears():
-            for p in (l.weight, l.bias):
-                n = p.numel()
-                out.append(flat[off:off + n].view(p.shape))
-                off += n
-        return out
+        return self._views_of(flat)
 
     @property
     def hip_cfg(self):

@@ -363,3 +363,55 @@ def test_empty_inputs_are_no_ops():
     assert lam.shape == (0, 3) and V.shape == (0, 3, 3) and mean.numel() == 0 and J.shape == (0, 3, 3)
     f, g = hip.query(cfg, th, torch.zeros(0, 3, device="cuda"))
     assert f.numel() == 0 and g.shape == (0, 3)
+
+
+@pytest.mark.parametrize("hidden", [[200] * 4, [256, 128, 256], [48, 100, 32], [300, 512]])
+def test_any_hidden_layer_config(hidden):
+    """The reference builds any list of widths (src/model.py:94-108).  Here a network runs at the smallest built width >=
+    its widest layer, zero-padded (exact for a sine MLP); state_dict, optimizer and gradients keep the caller's shapes and
+    no padded entry ever becomes non-zero."""
+    from src.model import SIREN
+    from src.loss_functions import loss_s1, loss_s2
+    from src.diff_operators import gradient, hessian
+    model, P = make_model(hidden, 31)
+    assert [tuple(v.shape) for v in model.state_dict().values()] == [s for w, b in P for s in (w.shape, b.shape)]
+    (x, nrm, sdf), (xd, nd, sd) = batch(450, 77)
+    x64, n64, s64 = x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64)
+    # value, df/dx, Hessian
+    out = model(xd)
+    y, xin = out["model_out"], out["model_in"]
+    y_ref, g_ref, H_ref = O.query(P, x64, want_hess=True)
+    assert rel(y[0, :, 0].detach().cpu().numpy(), y_ref) < 5e-6
+    assert rel(gradient(y, xin)[0].detach().cpu().numpy(), g_ref) < 2e-5
+    assert rel(hessian(y, xin)[0].cpu().numpy(), H_ref) < 5e-5
+    # losses and parameter gradients, reference loop usage (plain columns, Hessian quads, loss_s2's statistics)
+    for fn, mode, w, tol in ((loss_s1, "s1", W_S1EIK, 1e-4), (loss_s1, "s1", W_S1FULL, 5e-4), (loss_s2, "s2", W_S2, 1e-4)):
+        model.zero_grad()
+        loss = fn(model, xd, {"normals": nd, "sdf": sd}, w, 100)
+        total = torch.zeros((1, 1), device="cuda:0")
+        for l in loss.values():
+            total += l
+        total.backward()
+        t_ref, gr, _ = O.loss_and_grad(mode, P, x64, n64, s64, w, 100.0)
+        assert rel([v.item() for v in loss.values()], [float(v) for v in t_ref.values()]) < 2e-5
+        got = np.concatenate([p.grad.detach().reshape(-1).cpu().numpy() for p in model.parameters()])
+        assert got.size == sum(w_.size + b_.size for w_, b_ in P)           # the caller's shapes: no padded entry in a gradient
+        assert rel(got, flat(gr)) < tol, (hidden, mode, w)
+    # three optimizer steps: the padding stays exactly zero, the parameters stay views of the one buffer
+    opt = torch.optim.Adam(lr=1e-4, params=model.parameters())
+    n_real = sum(p.numel() for p in model.parameters())
+    for t in range(3):
+        opt.zero_grad()
+        loss = loss_s1(model, xd, {"normals": nd, "sdf": sd}, W_S1EIK, 100)
+        sum(l.sum() for l in loss.values()).backward()
+        opt.step()
+    theta = model.flat_parameters()
+    assert int((theta != 0).sum()) <= n_real and theta.numel() >= n_real and model._is_flat()
+    mask = torch.ones_like(theta, dtype=torch.bool)
+    for v in model.split_flat(mask):
+        v.fill_(False)
+    assert float(theta[mask].abs().max()) == 0.0 if mask.any() else True
+    m2 = SIREN(3, 1, hidden).to("cuda:0")
+    m2.load_state_dict(model.state_dict())
+    y2 = m2(xd)["model_out"]
+    assert torch.equal(y2, model(xd)["model_out"])
