@@ -106,8 +106,8 @@ int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
     if (lo.ncol_n > 0) {
         a.tile0 = (int)(lo.ncol_h / DUDF_TILE_PTS); a.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); a.hess = 0;
         rc = DUDF_E_UNSUPPORTED;
-        if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base, lo.H, lo.L)) rc = dudf_launch_sweep_bf16(base, lo.H, a, st);
-        if (rc == DUDF_E_UNSUPPORTED) {                           // width / variant without a bf16x6 kernel (queries at H = 512)
+        if (use_bf16_sweeps() && dudf_sweep_bf16_handles(base, lo.H, lo.L, a)) rc = dudf_launch_sweep_bf16(base, lo.H, a, st);
+        if (rc == DUDF_E_UNSUPPORTED) {                           // width / variant without a 16-bit-core kernel (queries at H = 512)
             if (base == SWEEP_FWD) a.store_s = a.store_c = 1;     // the f32 kernel only builds its stash-everything variant
             rc = dudf_launch_sweep(base, lo.H, a, st);
         }

@@ -151,6 +151,7 @@ enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
 // the same sweeps on the bf16 matrix cores at fp32 accuracy (plain columns, H = 256)
 bool dudf_sweep_bf16_supported(int which, int H, int L);
+bool dudf_sweep_bf16_handles(int which, int H, int L, const SweepArgs& a);
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st);
 int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 

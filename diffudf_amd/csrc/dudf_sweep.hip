@@ -344,7 +344,7 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
         case SWEEP_ADJ_REV:
             if (a.have_e) DUDF_GO(SWEEP_ADJ_REV, 1); else DUDF_GO(SWEEP_ADJ_REV, 0);
             break;
-        // Hessian-quad variants: not built for H = 512 (hipcc 7.2 emits illegal AGPR operands for them at 512 registers)
+        // Hessian-quad variants (all widths incl. 512: DPP sources are pinned to architectural VGPRs, dudf_sweep_common.h)
         case SWEEP_FWD_H:
             if (!a.store_s) return DUDF_E_BADMODE;
             DUDF_GO(SWEEP_FWD_H, 1);

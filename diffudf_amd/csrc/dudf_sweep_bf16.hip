@@ -1334,6 +1334,16 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// ... and with THESE stash flags (the 512-wide kernel is built for the training variants: what it leaves behind is also how
+// a layer's outputs reach the next one); run_sweep asks before it opens the profiling scope of a launch
+bool dudf_sweep_bf16_handles(int which, int H, int L, const SweepArgs& a) {
+    if (!dudf_sweep_bf16_supported(which, H, L)) return false;
+    if (H != 512) return true;
+    if (which == SWEEP_FWD) return a.store_s && a.store_c;
+    if (which == SWEEP_REV) return a.train != 0;
+    return true;
+}
+
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
     if (H == 512) return L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV;      // plain columns (training variants)
     return (H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;

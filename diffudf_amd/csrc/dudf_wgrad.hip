@@ -18,6 +18,7 @@
 // The two thin layers (3 inputs / 1 output) are a bandwidth-bound VALU reduction.
 #include "dudf_internal.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -963,7 +964,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
             attr2 = true;
         }
         // DUDF_WGRAD=bf16w keeps the per-wave split kernel for the 256-wide tiles (A/B testing)
-        static const bool per_wave = [] { const char* e = getenv("DUDF_WGRAD"); return e && e[0] == 'b' && e[4] == 'w'; }();
+        static const bool per_wave = [] { const char* e = getenv("DUDF_WGRAD"); return e && strncmp(e, "bf16w", 5) == 0; }();
         if constexpr (H == 256) {
             if (!per_wave) {
                 static bool attr3 = false;
@@ -1051,7 +1052,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
-    static const int ppb = [] { const char* e = getenv("DUDF_SMALL_PPB"); return e ? atoi(e) : 4096; }();   // A/B testing: with 16 feature-quad groups 4096 columns per block is best (0.096 ms;
+    static const int ppb = [] { const char* e = getenv("DUDF_SMALL_PPB"); const int v = e ? atoi(e) : 4096; return v >= 64 ? v : 4096; }();   // A/B testing: with 16 feature-quad groups 4096 columns per block is best (0.096 ms;
                                                                        // round 1: 1024 columns x 4 groups, 0.156 ms)
     s.pts_per_block = dudf_deterministic() ? (int)lo.ncols : ppb;
     const int grid = (int)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block);

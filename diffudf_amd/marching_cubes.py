@@ -5,9 +5,13 @@ Cython extension.
 
 The Lewiner look-up tables are NOT part of this package: like the reference's extension, the native entry point takes them
 as an argument (`LutProvider` there, a flat int8 buffer + offsets here).  `udf_mc_lewiner(..., luts=...)` accepts
-  * a dict {name: int8 array} in the reference's names (`CASES`, `TILING1` ... `SUBCONFIG13`, + the three `EDGESREL*`), or
-  * None: the reference's own `_marching_cubes_lewiner_luts` module is imported from `sys.path` (the file a user of the
-    reference already has next to its wrapper) and decoded exactly as the reference decodes it (:144-148).
+  * a dict {name: int8 array} in the reference's names (`CASES`, `TILING1` ... `SUBCONFIG13`, + the three `EDGESREL*`),
+  * a path (str): an `.npz` of those arrays (`save_luts_npz` writes one), a `_marching_cubes_lewiner_luts.py` file in the
+    reference's (shape, base64 text) encoding, or a directory holding one — `load_luts`,
+  * None: `load_luts()` without a path: the `DUDF_MESHUDF_LUTS` environment variable (same three forms), then a module
+    `_marching_cubes_lewiner_luts` importable from `sys.path` (the file a user of the reference already has next to its
+    wrapper; scikit-image ships the same tables), decoded exactly as the reference decodes it (:144-148).  Nothing found:
+    `MeshUDFError` that says so.  `generate_mc.py` and `train.py` pass a config key `luts_path` through.
 """
 import base64
 import ctypes
@@ -68,20 +72,61 @@ def _lib():
     return _LIB
 
 
-def load_reference_luts():
-    """The tables of the reference's own `_marching_cubes_lewiner_luts.py` (must be importable), decoded as the reference
-    does: (shape, base64 text) -> int8 array."""
-    try:
-        import _marching_cubes_lewiner_luts as mcluts
-    except ImportError as e:
-        raise MeshUDFError("the Lewiner look-up tables are an input of the MeshUDF extraction: pass luts={name: int8 array} "
-                           "or put the reference's src/marching_cubes/ (its _marching_cubes_lewiner_luts.py) on sys.path") from e
+def _decode_module(mcluts):
+    """Tables of a `_marching_cubes_lewiner_luts` module, decoded as the reference does: (shape, base64 text) -> int8 array."""
     out = dict(EDGESREL)
     for name in LUT_NAMES[3:]:
         shape, text = getattr(mcluts, name)
         ar = np.frombuffer(base64.decodebytes(text.encode("utf-8")), dtype="int8").copy()
         out[name] = ar.reshape(shape)
     return out
+
+
+def save_luts_npz(luts, path):
+    """Write a table set as the `.npz` `load_luts(path)` reads (one-off conversion of a reference checkout's tables)."""
+    np.savez_compressed(path, **{name: np.asarray(luts[name], dtype=np.int8) for name in LUT_NAMES})
+
+
+def load_luts(path=None):
+    """The 48 Lewiner tables as {name: int8 array}.  `path`: an .npz, a `_marching_cubes_lewiner_luts.py`, or a directory that
+    holds one; None: $DUDF_MESHUDF_LUTS, then the module on sys.path (see the module docstring).  Raises MeshUDFError."""
+    import importlib
+    import importlib.util
+    path = path or os.environ.get("DUDF_MESHUDF_LUTS")
+    if path:
+        if os.path.isdir(path):
+            path = os.path.join(path, "_marching_cubes_lewiner_luts.py")
+        if not os.path.exists(path):
+            raise MeshUDFError(f"look-up tables: {path} does not exist")
+        if path.endswith(".npz"):
+            z = np.load(path)
+            missing = [n for n in LUT_NAMES[3:] if n not in z.files]
+            if missing:
+                raise MeshUDFError(f"look-up tables: {path} lacks {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+            out = dict(EDGESREL)
+            out.update({n: np.asarray(z[n], dtype=np.int8) for n in LUT_NAMES if n in z.files})
+            return out
+        spec = importlib.util.spec_from_file_location("_dudf_user_luts", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return _decode_module(mod)
+    for name in ("_marching_cubes_lewiner_luts", "src.marching_cubes._marching_cubes_lewiner_luts",
+                 "skimage.measure._marching_cubes_lewiner_luts"):
+        try:
+            mod = importlib.import_module(name)
+        except Exception:
+            continue
+        if all(hasattr(mod, n) for n in LUT_NAMES[3:]):
+            return _decode_module(mod)
+    raise MeshUDFError("the Lewiner look-up tables are an INPUT of the MeshUDF extraction and are not shipped with this package: "
+                       "pass luts={name: int8 array} or luts='<path>' (an .npz written by marching_cubes.save_luts_npz, or the "
+                       "reference's src/marching_cubes/_marching_cubes_lewiner_luts.py), set DUDF_MESHUDF_LUTS to such a path, "
+                       "or put that module on sys.path")
+
+
+def load_reference_luts():
+    """Kept for callers of round 2: the tables found without an explicit path (`load_luts()`)."""
+    return load_luts()
 
 
 def _pack_luts(luts):
@@ -139,8 +184,8 @@ def udf_mc_lewiner(volume, grads, spacing=(1., 1., 1.), gradient_direction='desc
     if int(step_size) != 1 or mask is not None or not allow_degenerate or use_classic:
         raise NotImplementedError("step_size != 1, mask, use_classic and allow_degenerate=False are not used by the reference's "
                                   "MeshUDF path and are not built")
-    if luts is None:
-        luts = load_reference_luts()
+    if luts is None or isinstance(luts, (str, os.PathLike)):
+        luts = load_luts(luts)
     vertices, faces, normals, values = marching_cubes_udf(volume, grads, luts, avg_thresh, max_thresh)
     if not len(vertices):
         raise RuntimeError('No surface found at the given iso value.')

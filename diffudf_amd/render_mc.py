@@ -1,7 +1,8 @@
 # coding: utf-8
 """Field extraction and CAP-UDF meshing for the marching-cubes consumers — reference src/render_mc.py:20-99
 `extract_fields` and :201-256 `extract_mesh_CAP` (BASELINE config 5: the batched field+gradient query feeding CAP-UDF
-extraction, all on the device).  MeshUDF's marching cubes (:103-199) is not part of this path."""
+extraction, all on the device) — and :101-199 `extract_mesh_MESHUDF`, the MeshUDF marching cubes over the same fields, on
+the host (C++ library behind `marching_cubes.udf_mc_lewiner`; serial by nature)."""
 import numpy as np
 import torch
 
@@ -99,7 +100,9 @@ def extract_mesh_MESHUDF(df_values, normals, device, smooth_borders=False, luts=
     its (N, N, N, 3) direction field (outputs of `extract_fields`; tensors or numpy arrays), vertices shifted to
     [-1, 1]^3.  The extraction itself — the reference's Cython extension — is `diffudf_amd.marching_cubes.udf_mc_lewiner`
     over the host C++ library (bit-identical vertices and faces, tests/test_meshudf.py); the Lewiner tables come from the
-    caller (`luts=`) or from the reference's own `_marching_cubes_lewiner_luts.py` on `sys.path`.
+    caller (`luts=`: a dict or a path) or from `marching_cubes.load_luts()` ($DUDF_MESHUDF_LUTS, then the reference's own
+    `_marching_cubes_lewiner_luts.py` on `sys.path`); none found: MeshUDFError.  Tensors come back on `device`, as in
+    the reference.
     Returns (vertices, faces, mesh).  The reference then cleans the mesh with trimesh (`process`, duplicate / degenerate
     faces, `fill_holes`, optional Laplacian smoothing of the border): done the same way when trimesh is importable;
     without it the raw extraction is returned in a `TriangleSoup` (and `smooth_borders` is ignored)."""
@@ -117,7 +120,8 @@ def extract_mesh_MESHUDF(df_values, normals, device, smooth_borders=False, luts=
         import trimesh
     except ImportError:
         mesh = TriangleSoup(verts, faces)
-        return torch.from_numpy(np.ascontiguousarray(verts)).float(), torch.from_numpy(np.ascontiguousarray(faces)).long(), mesh
+        return (torch.from_numpy(np.ascontiguousarray(verts)).float().to(device),
+                torch.from_numpy(np.ascontiguousarray(faces)).long().to(device), mesh)
     mesh = trimesh.Trimesh(verts, faces).process(validate=False)
     mesh.remove_duplicate_faces(); mesh.remove_degenerate_faces(); mesh.fill_holes()
     mesh2 = trimesh.Trimesh(mesh.vertices, mesh.faces)
@@ -146,4 +150,4 @@ def extract_mesh_MESHUDF(df_values, normals, device, smooth_borders=False, luts=
             for _ in range(5):
                 avg = sp @ mesh.vertices / sp.sum(axis=1)
                 mesh.vertices[bv] = mesh.vertices[bv] + 0.3 * (np.asarray(avg) - mesh.vertices[bv])
-    return torch.tensor(mesh.vertices).float(), torch.tensor(mesh.faces).long(), mesh
+    return torch.tensor(mesh.vertices).float().to(device), torch.tensor(mesh.faces).long().to(device), mesh

@@ -16,9 +16,12 @@ What runs underneath is the MI355X path: the loss dict comes from the fused HIP 
 buffer), and under torch.distributed every rank takes its stratified share of the batch and the gradients
 are all-reduced over RCCL before the step.
 
-After training (reference train.py:403-446), when `resolution != 0`: the field slice of the best model (`generate_df`)
-and its CAP-UDF mesh (`generate_mc`, the CAP half of algorithm 'both'; MeshUDF's marching cubes is not part of this
-build) are written to `reconstructions/`; tensorboard is optional.
+After training (reference train.py:403-446): the field slice of the best model (`generate_df`, always, as in the
+reference) and, when `resolution != 0`, its meshes (`generate_mc` algorithm 'both': CAP-UDF on the device and MeshUDF's
+marching cubes in host C++; the latter needs the Lewiner tables — config key `luts_path`, $DUDF_MESHUDF_LUTS or the
+reference's table module on sys.path — and is skipped with a message when they are not there) are written to
+`reconstructions/`.  gt_mode 'siren' trains, but its post-training artefacts (skimage's SDF marching cubes) are outside
+this build: a message says so.  tensorboard is optional.
 """
 import argparse
 import copy
@@ -267,25 +270,31 @@ def setup_train(parameter_dict, cuda_device):
         n_pts = dataset.n_global * dataset.batchesPerEpoch * parameter_dict["num_epochs"]
         print(f"training time {training_time:.2f} s  ({n_pts / training_time:.3e} points/s)")
     meshes = []
-    if _is_main() and parameter_dict.get("resolution", 256) != 0:
-        # post-training artefacts as in reference train.py:403-446: the field slice of the best model and — CAP-UDF half of
-        # algorithm 'both' — its mesh, on the device (resolution 0, as the shipped configs here set it, skips both)
+    if _is_main():
+        # post-training artefacts as in reference train.py:403-446: the field slice of the best model (always) and, when
+        # `resolution != 0`, its meshes (algorithm 'both') — rank 0 only, the other ranks go on to tear down
         from generate_df import generate_df
         from generate_mc import generate_mc
         best = osp.join(full_path, "models", "model_best.pth")
-        if gt_mode == 'tanh' and osp.exists(best):
+        if gt_mode != 'tanh':
+            print(f"post-training artefacts skipped: gt_mode '{gt_mode}' needs skimage's SDF marching cubes, which is outside this build")
+        elif not osp.exists(best):
+            print(f"post-training artefacts skipped: {best} was never written (no epoch improved on the initial loss)")
+        else:
             print('Generating distance field slices')
             generate_df(best, None, osp.join(full_path, "reconstructions/"),
                         {'device': f"cuda:{int(device.index or 0)}", 'surf_thresh': 1e-3, 'width': 512, 'weight0': network_params["w0"],
                          'gt_mode': gt_mode, 'alpha': parameter_dict.get('alpha', 1),
                          'hidden_layer_nodes': network_params["hidden_layer_nodes"], 'activation': network_params.get('activation', 'sine')})
-            print('Generating mesh')
-            meshes = generate_mc(model=None, gt_mode=gt_mode, device=int(device.index or 0), N=parameter_dict.get('resolution', 256),
-                                 output_path=osp.join(full_path, "reconstructions", 'mc_mesh_best.obj'),
-                                 alpha=parameter_dict.get('alpha', 1), algorithm='both',
-                                 from_file={'w0': network_params["w0"], 'model_path': best,
-                                            'hidden_layer_nodes': network_params["hidden_layer_nodes"],
-                                            'activation': network_params.get('activation', 'sine')})
+            if parameter_dict.get('resolution', 256) != 0:
+                print('Generating mesh')
+                meshes = generate_mc(model=None, gt_mode=gt_mode, device=int(device.index or 0), N=parameter_dict.get('resolution', 256),
+                                     output_path=osp.join(full_path, "reconstructions", 'mc_mesh_best.obj'),
+                                     alpha=parameter_dict.get('alpha', 1), algorithm='both',
+                                     from_file={'w0': network_params["w0"], 'model_path': best,
+                                                'hidden_layer_nodes': network_params["hidden_layer_nodes"],
+                                                'activation': network_params.get('activation', 'sine')},
+                                     luts=parameter_dict.get('luts_path'))
     return training_time, meshes
 
 
