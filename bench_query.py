@@ -2,7 +2,7 @@
 # coding: utf-8
 """Secondary measurements (not the headline metric): inference-side queries of BASELINE configs 4 and 5.
 
-    python bench_query.py [--grid 256] [--rays 512]
+    python bench_query.py [--grid 256] [--rays 512] [--hidden 256]
 
 config 5: `extract_fields` field part on a grid^3 grid (value + df/dx + inverse map + normalisation), points/s;
 config 4: value + df/dx + Hessian + eigen-frame on rays^2 points, points/s.  One JSON line each."""
@@ -22,18 +22,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--rays", type=int, default=512)
+    ap.add_argument("--hidden", type=int, default=256, help="layer width of the 8-layer SIREN (512: BASELINE config 3's net)")
     args = ap.parse_args()
     from diffudf_amd import hip_ops, synth
     from diffudf_amd.model import SIREN
     from diffudf_amd.render_mc import extract_fields
-    hidden = [256] * 8
+    hidden = [args.hidden] * 8
     model = SIREN(3, 1, hidden)
     sd = {}
     for i, (w, b) in enumerate(synth.siren_params(hidden, seed=123)):
         sd[f"net.{i}.0.weight"] = torch.from_numpy(w); sd[f"net.{i}.0.bias"] = torch.from_numpy(b)
     model.load_state_dict(sd)
     model.to("cuda:0")
-    F0 = 2 * (3 * 256 + 7 * 256 * 256 + 256)
+    F0 = 2 * (3 * args.hidden + 7 * args.hidden * args.hidden + args.hidden)
     N = args.grid
     extract_fields(model, None, N, "tanh", "cuda:0", 100)              # warm: allocator, workspaces, code objects
     torch.cuda.synchronize(); t0 = time.perf_counter()

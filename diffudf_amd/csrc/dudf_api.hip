@@ -45,8 +45,13 @@ bool dudf_split_fp16() {
     return on;
 }
 // which plain-column sweeps run fp16x3: DUDF_SPLIT_SWEEPS = bit mask (bit 0 forward .. bit 3 adjoint reverse; A/B testing)
+// bit 5: the 512-wide Hessian-quad / jet sweeps as well (DUDF_SPLIT_QUADS=0: bf16x6)
 int dudf_split_mask() {
-    static const int m = [] { const char* e = getenv("DUDF_SPLIT_SWEEPS"); return e ? atoi(e) & 15 : 15; }();
+    static const int m = [] {
+        const char* e = getenv("DUDF_SPLIT_SWEEPS");
+        const char* q = getenv("DUDF_SPLIT_QUADS");
+        return (e ? atoi(e) & 15 : 15) | ((q && q[0] == '0') ? 0 : 32);
+    }();
     return dudf_split_fp16() ? m : 0;
 }
 
@@ -141,8 +146,8 @@ int forward_common(Ctx& c, const float* theta, const float* x, int train, bool r
     // and W^T are packed only when a kernel that reads them can run: everything except a training step of plain columns
     // whose four sweeps are all fp16x3 (Hessian quads, jets, A/B modes, very deep nets: bf16x6; f32-input kernels: W^T).
     const DudfLayout& lo = c.lo;
-    const bool all16 = train && lo.ncol_h == 0 && use_bf16_sweeps() && dudf_split_mask() == 15 && lo.L <= 32;
-    const int need = (all16 ? 0 : 1) | ((!use_bf16_sweeps() || (lo.H == 512 && (lo.ncol_h > 0 || !train))) ? 2 : 0);
+    const bool all16 = train && lo.ncol_h == 0 && use_bf16_sweeps() && (dudf_split_mask() & 15) == 15 && lo.L <= 32;
+    const int need = (all16 ? 0 : 1) | (!use_bf16_sweeps() ? 2 : 0);
     rc = (lo.L >= 2) ? dudf_launch_prep(lo, theta, x, c.ws, need, c.st) : DUDF_E_UNSUPPORTED;
     if (rc == DUDF_E_UNSUPPORTED) {                     // widths without 16-bit weight images: the separate kernels
         if ((rc = dudf_launch_pack(c.lo, theta, c.ws, c.st))) return rc;
@@ -271,7 +276,7 @@ int dudf_query_frame(const dudf_net_cfg* cfg, const float* theta, const float* x
 
 namespace {
 // curvature query workspace = [Hessian-query layout of n points][lam 3n][V 9n][jet x4 4*npj][jet y npj]
-struct CurvLayout { DudfLayout q; int64_t npj, o_lam, o_V, o_x4, o_y; size_t total_bytes; };
+struct CurvLayout { DudfLayout q; int64_t npj, o_lam, o_V, o_x4, o_y, o_relay; size_t total_bytes; };
 int make_curv_layout(const dudf_net_cfg* cfg, int64_t n, CurvLayout* cl) {
     int rc = dudf_make_layout(cfg, n, n, &cl->q, 1);
     if (rc) return rc;
@@ -281,6 +286,9 @@ int make_curv_layout(const dudf_net_cfg* cfg, int64_t n, CurvLayout* cl) {
     int64_t o = (int64_t)(cl->q.total_bytes / sizeof(float));
     auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) / 4 * 4; return r; };
     cl->o_lam = take(3 * n); cl->o_V = take(9 * n); cl->o_x4 = take(4 * cl->npj); cl->o_y = take(cl->npj);
+    // 512-wide layers: a layer's outputs reach the next one through memory (dudf_sweep_bf16.hip, sweep_tile_w) — one layer's
+    // worth of the jet columns, reused by every layer
+    cl->o_relay = cl->q.H == 512 ? take((int64_t)cl->q.H * cl->npj) : cl->o_y;
     cl->total_bytes = (size_t)o * sizeof(float);
     return 0;
 }
@@ -314,6 +322,7 @@ int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const floa
     if ((rc = dudf_launch_make_x4_jet(x, V, n, cl.npj, c.ws + cl.o_x4, c.st))) return rc;
     SweepArgs a = make_sweep_args(c.lo, theta, c.ws);
     a.x4 = c.ws + cl.o_x4; a.y = c.ws + cl.o_y; a.np = cl.npj; a.stash_layer = (int64_t)c.lo.H * cl.npj;
+    if (c.lo.H == 512) { a.S = c.ws + cl.o_relay; a.stash_layer = 0; }     // every layer's slot is the same one
     a.tile0 = 0; a.ntiles = (int)(cl.npj / DUDF_TILE_PTS); a.hess = 1;
     if (use_bf16_sweeps() && dudf_sweep_bf16_supported(SWEEP_FWD_J, c.lo.H, c.lo.L)) rc = dudf_launch_sweep_bf16(SWEEP_FWD_J, c.lo.H, a, c.st);
     else rc = dudf_launch_sweep(SWEEP_FWD_J, c.lo.H, a, c.st);

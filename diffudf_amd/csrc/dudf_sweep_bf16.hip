@@ -972,11 +972,19 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
 //     every wait is hand-counted (derivation at the waits); around a tail burst everything is drained once per layer.
 // Cost against the register-resident scheme: one more stash unit READ per layer and sweep (largely served by L2 / the
 // Infinity Cache: it is the unit just written), and the burst is not overlapped with this wave's own MFMAs.
-template <int SW> struct WideIn;                        // which stash array carries the post-tail values of sweep SW
-template <> struct WideIn<SWEEP_FWD> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.S; } };
-template <> struct WideIn<SWEEP_REV> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.Q; } };
-template <> struct WideIn<SWEEP_ADJ_FWD> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.A; } };
-template <> struct WideIn<SWEEP_ADJ_REV> { static __device__ __forceinline__ const float* arr(const SweepArgs& a) { return a.Z; } };
+// which stash array carries the post-tail values of sweep SW to the next layer.  Where the tail does not store them itself
+// (queries: the reverse sweep without its training stores, the jets) the kernel stores them into S, which no later tail of
+// the same sweep reads.
+template <int SW, int FL>
+__device__ __forceinline__ const float* wide_in(const SweepArgs& a) {
+    constexpr int BS = base_of(SW);
+    if constexpr (BS == SWEEP_FWD) return a.S;
+    else if constexpr (BS == SWEEP_REV) return (FL & 1) ? a.Q : a.S;
+    else if constexpr (BS == SWEEP_ADJ_FWD) return a.A;
+    else return a.Z;
+}
+template <int SW, int FL>
+constexpr bool wide_relay_store() { return (base_of(SW) == SWEEP_REV && !(FL & 1)) || SW == SWEEP_FWD_J; }
 
 template <int SP>
 struct GeoWT {
@@ -997,13 +1005,15 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     using G = GeoWT<SP>;
     constexpr int H = G::H;
     constexpr int NPC = G::NPC;
-    constexpr bool kColScale = SP != 0 && SW != SWEEP_FWD;
-    static_assert(SW <= SWEEP_ADJ_REV, "plain columns only");
+    constexpr int BS = base_of(SW);
+    constexpr bool HS = is_hess(SW);                   // Hessian quads / jets: the tails couple lanes (dudf_sweep_common.h)
+    constexpr bool kColScale = SP != 0 && SW != SWEEP_FWD;   // (the quads' forward tangents are not bounded by 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
+    const bool isv = !HS || (is_jet(SW) ? li == 0 : (lane & 3) == 0);
     const int nhid = a.L - 1;
-    constexpr bool kFwdDir = (SW == SWEEP_FWD || SW == SWEEP_ADJ_FWD);
+    constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
     const int64_t p = (int64_t)(g_first + wave) * 16 + li;
     auto image = [&](int j) -> const char* {
         if constexpr (SP) return kFwdDir ? a.wimg16_f + (size_t)j * G::IMGB : a.wimg16_t + (size_t)(nhid - 1 - j) * G::IMGB;
@@ -1063,11 +1073,12 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         // operand ring: the stash operands of tile T + PD are requested when tile T has been consumed.  One tile of tail is
         // ~100 instructions, an HBM round trip ~2 us: with the operands only one tile ahead the burst waited for memory at
         // every tile (it took about as long as the layer's whole k-loop); the forward sweep only reads its bias (cached).
-        constexpr int PD = (SW == SWEEP_FWD) ? 2 : 8;
+        // (three-operand tails — the quads' adjoint sweeps — get a ring of four: 128 accumulator registers leave no more)
+        constexpr int PD = (BS == SWEEP_FWD) ? 2 : ((SW == SWEEP_ADJ_FWD_H || SW == SWEEP_ADJ_REV_H) ? 4 : 8);
         f32x4 o1[PD], o2[PD], o3[PD], bs[PD];
         auto ld = [&](int T, int s) {
             epilogue_loads<SW, FL>(a, stash_base(layer, T), vo, o1[s], o2[s], o3[s]);
-            if constexpr (SW == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
+            if constexpr (BS == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
         };
         float cmax = 0.f;                              // fp16x3: largest |output| of this lane's rows of the column
 #pragma unroll
@@ -1076,17 +1087,20 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         for (int T = 0; T < G::NT; ++T) {
             const int s = T % PD;
             f32x4 z = acc[T];
+            const f32x4 zero4 = {0, 0, 0, 0};
             if constexpr (SP != 0 && SW == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[s]);
             else if constexpr (SW == SWEEP_FWD) z += bs[s];
+            else if constexpr (BS == SWEEP_FWD) z = (SP != 0 ? z * unscale : z) + (isv ? bs[s] : zero4);   // the bias: value channel only
             else if constexpr (SP != 0) z *= unscale;
-            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, true, tmax);
+            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, isv, tmax);
+            if constexpr (wide_relay_store<SW, FL>()) DUDF_ST(a.S, stash_base(layer, T), vo, e);
             if constexpr (kColScale) dudf_track(cmax, e);
             if (T + PD < G::NT) ld(T + PD, s);
             if (last) {
-                if constexpr (SW == SWEEP_FWD) {
+                if constexpr (BS == SWEEP_FWD) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q);
                     part += e[0] * wv[0] + e[1] * wv[1] + e[2] * wv[2] + e[3] * wv[3];
-                } else if constexpr (SW == SWEEP_REV) {
+                } else if constexpr (BS == SWEEP_REV) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w1t16 + li * H + 16 * T + 4 * q);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) accg = mfma16(wv[t], e[t], accg);
@@ -1107,9 +1121,10 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     // ---- first layer (fp32, K = 3): pre-activations / incoming adjoints of the 32 tiles, then their tails ----
     {
         float b = 0.f, yb = 1.f;
-        if constexpr (SW == SWEEP_FWD) b = (q < 3) ? a.x4[p * 4 + q] : 0.f;
-        if constexpr (SW == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;
-        if constexpr (SW == SWEEP_ADJ_REV) yb = a.ybar[p];
+        if constexpr (BS == SWEEP_FWD) b = (q < 3) ? a.x4[p * 4 + q] : 0.f;
+        if constexpr (BS == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;
+        if constexpr (BS == SWEEP_ADJ_REV) yb = a.ybar[p];
+        if constexpr (SW == SWEEP_REV_H) yb = isv ? 1.f : 0.f;                         // adot_L^k = 0
 #pragma unroll
         for (int T = 0; T < G::NT; ++T) {
             if constexpr (kFwdDir) acc[T] = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
@@ -1122,7 +1137,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
 
     // read-back of the post-tail values of tiles 2kb, 2kb+1 of `layer`: two asm loads, scalar base + lane offset
     auto ld_in = [&](int layer, int kb, f32x4& x0, f32x4& x1) {
-        const float* b0 = WideIn<SW>::arr(a) + stash_base(layer, 2 * kb);
+        const float* b0 = wide_in<SW, FL>(a) + stash_base(layer, 2 * kb);
         const float* b1 = b0 + 16 * a.np;              // next tile: 16 feature rows further (stash_base is linear in T)
         const uint64_t g0 = (uint64_t)(size_t)b0, g1 = (uint64_t)(size_t)b1;
         // (readfirstlane returns int: go through unsigned, or a low word with its top bit set sign-extends into the high word)
@@ -1232,12 +1247,12 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         }
 #endif
     }
-    if constexpr (SW == SWEEP_FWD) {
+    if constexpr (BS == SWEEP_FWD) {
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        part += a.theta[a.off_bo];
+        if (isv) part += a.theta[a.off_bo];             // tangent / jet columns are derivatives: no constant term
         if (q == 0) a.y[p] = part;
-    } else if constexpr (SW == SWEEP_REV) {
+    } else if constexpr (BS == SWEEP_REV) {
         if (q == 0) *reinterpret_cast<f32x4*>(a.g + p * 4) = f32x4{accg[0], accg[1], accg[2], 0.f};
     }
 }
@@ -1311,42 +1326,40 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
         }                                                                                                   \
         hipLaunchKernelGGL((sweep_w16_kernel<SW, FL>), dim3(grid), dim3(G::NTHR), smem16, st, a);           \
     } while (0)
-    if (which <= SWEEP_ADJ_REV && ((a.split >> which) & 1)) {          // fp16x3 (DUDF_SPLIT, DUDF_SPLIT_SWEEPS)
-        bool done = true;
-        if (which == SWEEP_FWD && a.store_s && a.store_c) DUDF_GO_W16(SWEEP_FWD, 3);
-        else if (which == SWEEP_REV && a.train) DUDF_GO_W16(SWEEP_REV, 1);
-        else if (which == SWEEP_ADJ_FWD) DUDF_GO_W16(SWEEP_ADJ_FWD, 0);
-        else if (which == SWEEP_ADJ_REV) { if (a.have_e) DUDF_GO_W16(SWEEP_ADJ_REV, 1); else DUDF_GO_W16(SWEEP_ADJ_REV, 0); }
-        else done = false;
-        if (done) return (int)hipGetLastError();
-    }
-#undef DUDF_GO_W16
-    switch (which) {                                    // training variants only: queries at this width stay on the f32 kernel
-        case SWEEP_FWD: if (a.store_s && a.store_c) DUDF_GO_W(SWEEP_FWD, 3); else return DUDF_E_UNSUPPORTED; break;
-        case SWEEP_REV: if (a.train) DUDF_GO_W(SWEEP_REV, 1); else return DUDF_E_UNSUPPORTED; break;
-        case SWEEP_ADJ_FWD: DUDF_GO_W(SWEEP_ADJ_FWD, 0); break;
-        case SWEEP_ADJ_REV: if (a.have_e) DUDF_GO_W(SWEEP_ADJ_REV, 1); else DUDF_GO_W(SWEEP_ADJ_REV, 0); break;
+    // fp16x3 or bf16x6: plain columns by their DUDF_SPLIT_SWEEPS bit, quads and jets by bit 5 (DUDF_SPLIT_QUADS)
+    const bool h16 = which <= SWEEP_ADJ_REV ? ((a.split >> which) & 1) != 0 : (a.split & 32) != 0;
+#define DUDF_W(SW, FL) do { if (h16) DUDF_GO_W16(SW, FL); else DUDF_GO_W(SW, FL); } while (0)
+    // The stash array a layer's outputs travel through is written in every variant (wide_in): the forward sweeps always
+    // store h_l (a value-only query: nothing else), the query variants of the reverse sweeps park q_l in S.
+    switch (which) {
+        case SWEEP_FWD: if (a.store_c) DUDF_W(SWEEP_FWD, 3); else DUDF_W(SWEEP_FWD, 1); break;
+        case SWEEP_REV: if (a.train) DUDF_W(SWEEP_REV, 1); else DUDF_W(SWEEP_REV, 0); break;
+        case SWEEP_ADJ_FWD: DUDF_W(SWEEP_ADJ_FWD, 0); break;
+        case SWEEP_ADJ_REV: if (a.have_e) DUDF_W(SWEEP_ADJ_REV, 1); else DUDF_W(SWEEP_ADJ_REV, 0); break;
+        case SWEEP_FWD_H: DUDF_W(SWEEP_FWD_H, 1); break;
+        case SWEEP_REV_H: if (a.train) DUDF_W(SWEEP_REV_H, 1); else DUDF_W(SWEEP_REV_H, 0); break;
+        case SWEEP_ADJ_FWD_H: DUDF_W(SWEEP_ADJ_FWD_H, 0); break;
+        case SWEEP_ADJ_REV_H: DUDF_W(SWEEP_ADJ_REV_H, 0); break;
+        case SWEEP_FWD_J: DUDF_W(SWEEP_FWD_J, 0); break;
         default: return DUDF_E_UNSUPPORTED;
     }
+#undef DUDF_W
+#undef DUDF_GO_W16
 #undef DUDF_GO_W
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-// ... and with THESE stash flags (the 512-wide kernel is built for the training variants: what it leaves behind is also how
-// a layer's outputs reach the next one); run_sweep asks before it opens the profiling scope of a launch
+// ... and with THESE stash flags; run_sweep asks before it opens the profiling scope of a launch.  (Round 2: the 512-wide kernel
+// was built for the training variants only; now every variant is.)
 bool dudf_sweep_bf16_handles(int which, int H, int L, const SweepArgs& a) {
-    if (!dudf_sweep_bf16_supported(which, H, L)) return false;
-    if (H != 512) return true;
-    if (which == SWEEP_FWD) return a.store_s && a.store_c;
-    if (which == SWEEP_REV) return a.train != 0;
-    return true;
+    (void)a;
+    return dudf_sweep_bf16_supported(which, H, L);
 }
 
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
-    if (H == 512) return L >= 2 && which >= SWEEP_FWD && which <= SWEEP_ADJ_REV;      // plain columns (training variants)
-    return (H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
+    return (H == 512 || H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
 }
 
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a0, hipStream_t st) {

@@ -66,6 +66,32 @@ def _f32(t, what):
     return t.contiguous()
 
 
+_theta_counts = {}
+
+
+def _check_theta(cfg, theta):
+    key = (cfg.n_hidden_layers, cfg.hidden)
+    n = _theta_counts.get(key)
+    if n is None:
+        n = _theta_counts[key] = theta_count(cfg)
+    if theta.numel() != n or theta.dtype != torch.float32 or theta.device.type != "cuda":
+        raise _lib.DudfError(f"theta must be {n} fp32 elements on the GPU for SIREN(3, 1, [{cfg.hidden}]*{cfg.n_hidden_layers}); got "
+                             f"{theta.numel()} x {theta.dtype} on {theta.device}")
+
+
+def _theta(cfg, theta):
+    """theta as the C ABI takes it: flat fp32 on the GPU with exactly this network's (padded) parameter count — the library
+    indexes it by the layout of `cfg` and cannot know the length of the buffer behind a pointer."""
+    theta = _f32(theta, "theta")
+    key = (cfg.n_hidden_layers, cfg.hidden)
+    n = _theta_counts.get(key)
+    if n is None:
+        n = _theta_counts[key] = theta_count(cfg)
+    if theta.numel() != n:
+        raise _lib.DudfError(f"theta has {theta.numel()} elements; SIREN(3, 1, [{cfg.hidden}]*{cfg.n_hidden_layers}) takes {n}")
+    return theta
+
+
 class Workspace:
     """Caller-owned scratch for one (cfg, n_points, n_hess).  Holds the stash between forward and backward."""
 
@@ -116,7 +142,7 @@ def query(cfg, theta, x, want_grad=True, ws=None):
     """f (n,), df/dx (n,3) or None.  Reference: src/evaluate.py:26-32 per chunk."""
     lib = _lib.load()
     x = _f32(x, "x").view(-1, 3)
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     n = x.shape[0]
     ws = ws or query_workspace_for(cfg, n, x.device)
     f = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -131,7 +157,7 @@ def query_hessian(cfg, theta, x, ws=None):
     """f (n,), df/dx (n,3), Hessian (n,3,3) [i][k] = d(df/dx_i)/dx_k.  Reference: src/evaluate.py:26-35."""
     lib = _lib.load()
     x = _f32(x, "x").view(-1, 3)
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     n = x.shape[0]
     ws = ws or query_workspace_for(cfg, n, x.device, n_hess=n)
     f = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -148,7 +174,7 @@ def query_frame(cfg, theta, x, ws=None):
     lower triangle (reference src/render_st.py:57-62)."""
     lib = _lib.load()
     x = _f32(x, "x").view(-1, 3)
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     n = x.shape[0]
     ws = ws or query_workspace_for(cfg, n, x.device, n_hess=n)
     dev = x.device
@@ -167,7 +193,7 @@ def query_curvature(cfg, theta, x, want_shape=False, chunk=65536):
     J (n,3,3) = d normal_i / d x_k; (None, None) otherwise.  Runs in chunks so the scratch stays a few GB."""
     lib = _lib.load()
     x = _f32(x, "x").view(-1, 3)
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     n, dev = x.shape[0], x.device
     lam = torch.empty(n, 3, dtype=torch.float32, device=dev); v = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
     mean = torch.empty(n, dtype=torch.float32, device=dev)
@@ -195,7 +221,7 @@ def trace_rays(cfg, theta, rays, t0, mask, gt_mode, alpha, surface_threshold, ma
     """The marching loop of reference src/render_st.py:136-161 on the device.  rays (m,3), t0 (m,3) float64 CUDA tensors,
     mask (m,) uint8; t0 and mask are updated in place.  Returns (hits (m,) uint8, iterations executed)."""
     lib = _lib.load()
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     m = t0.shape[0]
     for t, dt in ((rays, torch.float64), (t0, torch.float64), (mask, torch.uint8)):
         if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
@@ -213,7 +239,7 @@ def trace_rays(cfg, theta, rays, t0, mask, gt_mode, alpha, surface_threshold, ma
 def descend_rays(cfg, theta, t0, hits, gt_mode, alpha, gd_steps, min_step=0.01):
     """`grad_descent` of reference src/render_st.py:163-172 on the device; t0 (m,3) float64 updated in place."""
     lib = _lib.load()
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     m = t0.shape[0]
     ws = query_workspace_for(cfg, m, t0.device)
     rc = lib.dudf_descend_rays(ctypes.byref(cfg), _ptr(theta), _ptr(t0), _ptr(hits), m, INVERSE_MODES[gt_mode],
@@ -225,7 +251,7 @@ def grid_fields(cfg, theta, grid_n, start, count, gt_mode, alpha, out_df, out_ve
     """Fills out_df[start:start+count], out_vec[start:start+count] (device tensors over the flattened N^3 grid);
     returns the device int32 counter of points that need the Hessian-eigenvector fallback."""
     lib = _lib.load()
-    theta = _f32(theta, "theta")
+    theta = _theta(cfg, theta)
     ws = ws or query_workspace_for(cfg, count, theta.device)
     flag = torch.zeros(1, dtype=torch.int32, device=theta.device)
     df = out_df[start:start + count]
@@ -275,6 +301,7 @@ def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws
     """n_hess > 0 (loss_s1 with a Hessian weight): the first n_hess points must be exactly the on-surface ones.
     `out`: a contiguous float32 tensor of 4 to receive the terms (no extra copy kernel in the training loop)."""
     lib = _lib.load()
+    _check_theta(cfg, theta)
     n = x.shape[0]
     terms = out if out is not None else torch.empty(4, dtype=torch.float32, device=x.device)
     rc = lib.dudf_loss_forward(ctypes.byref(cfg), mode, _ptr(theta), _ptr(x), _ptr(normals), _ptr(sdf), n,
@@ -286,6 +313,7 @@ def loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws
 
 def s2_forward_stats(cfg, theta, x, sdf, ws):
     lib = _lib.load()
+    _check_theta(cfg, theta)
     stats = torch.empty(3, dtype=torch.float64, device=x.device)
     rc = lib.dudf_s2_forward_stats(ctypes.byref(cfg), _ptr(theta), _ptr(x), _ptr(sdf), x.shape[0], _ptr(stats),
                                    _ptr(ws.buf), ws.nbytes, _stream())
@@ -317,6 +345,7 @@ def loss_backward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, c
 def loss_backward_sweeps(cfg, mode, theta, normals, sdf, n_global, weights, alpha, cot, stats, ws, n_local, n_hess=0):
     """loss cotangents + adjoint sweeps; the weight gradients follow through `weight_gradient` (layer ranges)."""
     lib = _lib.load()
+    _check_theta(cfg, theta)
     rc = lib.dudf_loss_backward_sweeps(ctypes.byref(cfg), mode, _ptr(theta), _ptr(normals), _ptr(sdf), int(n_local), int(n_global),
                                        int(n_hess), _w4(weights), float(alpha), _ptr(cot), _ptr(stats), _ptr(ws.buf), ws.nbytes,
                                        _stream())
@@ -343,6 +372,7 @@ def weight_gradient(cfg, n_local, have_g, layer_begin, layer_end, dtheta, ws, ac
 def fields_forward(cfg, theta, x, ws):
     """(f (n,), df/dx (n,3)) with the training stash kept in ws (for fields_backward)."""
     lib = _lib.load()
+    _check_theta(cfg, theta)
     n = x.shape[0]
     f = torch.empty(n, dtype=torch.float32, device=x.device)
     g = torch.empty(n, 3, dtype=torch.float32, device=x.device)
@@ -354,6 +384,7 @@ def fields_forward(cfg, theta, x, ws):
 
 def fields_backward(cfg, theta, x, ybar, gbar, ws, dtheta=None, accumulate=False):
     lib = _lib.load()
+    _check_theta(cfg, theta)
     if dtheta is None:
         dtheta = torch.empty_like(theta)
         accumulate = False

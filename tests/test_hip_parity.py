@@ -229,12 +229,17 @@ def test_unsupported_configs_fail_loudly(hip):
     th = torch.zeros(hip.theta_count(cfg), device="cuda")
     with pytest.raises(_lib.DudfError):      # a Hessian range with a loss that has no Hessian term
         hip.loss_forward(cfg, hip.LOSS_SIREN, th, z, z, z[:, 0].contiguous(), 128, [1, 1, 1, 1], 100.0, ws, n_hess=4)
-    with pytest.raises(_lib.DudfError):
-        hip.make_cfg([64, 32])
-    with pytest.raises(_lib.DudfError):
-        hip.query(hip.make_cfg([48, 48]), th, z)
-    with pytest.raises(_lib.DudfError):      # widths beyond the built set
-        hip.query_hessian(hip.make_cfg([1024] * 2), torch.zeros(8, device="cuda"), z)
+    # any list of widths runs at the smallest built width >= its widest layer (round 3; tests/test_api_gpu.py::
+    # test_any_hidden_layer_config) ...
+    assert hip.make_cfg([64, 32]).hidden == 64 and hip.make_cfg([48, 48]).hidden == 64 and hip.make_cfg([300, 20]).hidden == 512
+    with pytest.raises(_lib.DudfError):      # ... but theta must have that network's (padded) size,
+        hip.query(hip.make_cfg([48, 48, 48]), th, z)
+    with pytest.raises(_lib.DudfError):      # widths beyond the built set,
+        hip.make_cfg([1024] * 2)
+    with pytest.raises(_lib.DudfError):      # empty / non-positive widths
+        hip.make_cfg([64, 0])
+    with pytest.raises(_lib.DudfError):      # and anything but 3-D points -> scalar field still have no HIP path
+        hip.make_cfg([64, 64], n_in=2)
 
 
 def test_f32_and_bf16x6_sweeps_agree():
