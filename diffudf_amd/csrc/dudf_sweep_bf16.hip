@@ -43,6 +43,9 @@
 #ifndef DUDF_HI_DMA
 #define DUDF_HI_DMA 0                        // partial passes: the idle half issues the DMA pieces (measured: no gain)
 #endif
+#ifndef DUDF_TSPLIT
+#define DUDF_TSPLIT 0
+#endif
 #ifndef DUDF_ONESET
 #define DUDF_ONESET 0
 #endif
@@ -470,6 +473,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 if constexpr (!kOneSet) load_after_next(ops_n1);          // one full step ahead
             };
             u32x4 nb[NPC];
+            f32x4 te0 = {0, 0, 0, 0};
             // fp16x3: the half that does not multiply first runs its tail at the very top of the step, in front of its DMA
             // pieces (fetched two steps ahead: no hurry) and of its first LDS fragment: the step is (tail of one half beside the
             // MFMAs of the other) twice, and neither tail should wait for anything
@@ -552,7 +556,26 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                     DUDF_STAMP(7);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (kb + 1 < G::NKB && ((TA >= T && TA <= Tl && !late && !kTailTop) || (TB >= T && TB <= Tl && late))) {   // the next step's B operand
+                // DUDF_TSPLIT (fp16x3, stash-bound sweeps): the pair's two tiles run their tails half a step apart — loads waited
+                // for, stores issued in two smaller bursts instead of one
+                constexpr bool kTSplit = DUDF_TSPLIT && kColScale && !kOneSet;
+                constexpr int TA1 = TA, TA2 = TA + G::NT / 2, TB1 = TB - G::NT / 2, TB2 = TB;
+                if constexpr (kTSplit) {
+                    if (kb + 1 < G::NKB && ((TA1 >= T && TA1 <= Tl && !late) || (TB1 >= T && TB1 <= Tl && late))) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("" : "+v"(ops_cur.o1a), "+v"(ops_cur.o2a));
+                        te0 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 2] * unscale, ops_cur.o1a, ops_cur.o2a, ops_cur.o3a, stash_base(lin, 2 * kb + 2), vo, isv, tmax);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (kb + 1 < G::NKB && ((TA2 >= T && TA2 <= Tl && !late) || (TB2 >= T && TB2 <= Tl && late))) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("" : "+v"(ops_cur.o1b), "+v"(ops_cur.o2b));
+                        const f32x4 te1 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 3] * unscale, ops_cur.o1b, ops_cur.o2b, ops_cur.o3b, stash_base(lin, 2 * kb + 3), vo, isv, tmax);
+                        split(te0, te1, nb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (!kTSplit && kb + 1 < G::NKB && ((TA >= T && TA <= Tl && !late && !kTailTop) || (TB >= T && TB <= Tl && late))) {   // the next step's B operand
                     if (T != 0) __builtin_amdgcn_sched_barrier(0);
                     DUDF_STAMP(2);
 #ifdef DUDF_MPRIO

@@ -401,6 +401,13 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
 // VAR bit 1: the split of the next stage is cut into four feature slices issued BETWEEN the four MFMA groups of this
 //   stage instead of in front of them: the two waves of a SIMD then leave the post-barrier lockstep (both splitting,
 //   matrix core idle) after the first slice — one wave's slice runs beside the other's MFMAs.
+#ifndef DUDF_WG_NT
+// Cache policy of the staging loads.  A lane's four loads sit 64 bytes apart, so every 128-byte line is touched by two
+// different instructions; with the non-temporal hint (round 1-2) the second one missed L2 again: PMC FETCH_SIZE 4.17 GB per
+// launch against 2.87 GB of operands, 3.04 GB without the hint, and 0.65-0.68 ms instead of 0.76-0.80 (round 3,
+// tools/pmc_fetch.sh; profiles/r03_wgrad_nt.txt).  A/B: -DDUDF_WG_NT='" nt"'.
+#define DUDF_WG_NT ""
+#endif
 #ifndef DUDF_WG_HREL
 #define DUDF_WG_HREL 2             // flag-synchronised variant: hand the matrix pipe over this many MFMA groups before the end of a stage
 #endif
@@ -458,7 +465,8 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     const int tz = a.Hs / H;
     const int o_off = (blockIdx.z / tz) * H, i_off = (blockIdx.z % tz) * H;
     const int64_t xrow = (int64_t)(o_off / 4) * a.np * 4, yrow = (int64_t)(i_off / 4) * a.np * 4;
-    const bool clk_on = a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    // (fp16x3 build only: the bf16x6 build sits at 256 registers and four more live scalars make it spill)
+    const bool clk_on = SP != 0 && a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     f32x16 acc[W::MT][W::NTL];
@@ -521,8 +529,8 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         const uint64_t g0 = (uint64_t)(size_t)((pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * KB * 4);
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
         const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
-        asm volatile("global_load_dwordx4 %0, %4, %5 nt\n\tglobal_load_dwordx4 %1, %4, %5 offset:64 nt\n\t"
-                     "global_load_dwordx4 %2, %4, %5 offset:128 nt\n\tglobal_load_dwordx4 %3, %4, %5 offset:192 nt"
+        asm volatile("global_load_dwordx4 %0, %4, %5" DUDF_WG_NT "\n\tglobal_load_dwordx4 %1, %4, %5 offset:64" DUDF_WG_NT "\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:128" DUDF_WG_NT "\n\tglobal_load_dwordx4 %3, %4, %5 offset:192" DUDF_WG_NT
                      : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3) : "v"(p_voff), "s"(sbase) : "memory");
     };
     // outside the steady-state loop (prologue, last stages: conditional loads) the loads are ordinary ones: a conditional

@@ -132,4 +132,7 @@ def test_wgrad_register_staging_contract(tmp_path):
             assert res["scratch"] == 0, var
         else:
             assert res["scratch"] <= 2, var
+    # the fp16x3 build of the same body (round 3: the default): same contract
+    res = analyse_wgrad_presplit(asm, 9, "f16")
+    assert res["loads"] == 12 and res["carried"] == 12 and not res["bad"] and res["scratch"] == 0, res
 

@@ -3,6 +3,9 @@
 //   mode 0: copy (1 read : 1 write)   1: read only   2: write only   3: 2 reads : 2 writes (reverse / adjoint-forward sweep)
 //   shape 0: linear (a wave-instruction = 1 KiB contiguous)
 //   shape 1: stash (a wave-instruction = 4 x 256 B, the four feature-quad rows of a 16-column tile, rows np*16 B apart)
+//   shape 2 (read only; `wgrad` argument): the weight-gradient GEMM's staging loads — a wave-instruction = 16 rows x 64 B
+//            (4 lanes x 16 B), four instructions at +0, +64, +128, +192 B cover 256 B of each row; known byte count for
+//            calibrating FETCH_SIZE on this access shape:  rocprofv3 --pmc FETCH_SIZE -- dbg/hbm_stream wgrad
 // build: hipcc --offload-arch=gfx950 -O3 tools/micro/hbm_stream.hip -o dbg/hbm_stream ; run: dbg/hbm_stream
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -62,6 +65,23 @@ __global__ __launch_bounds__(512) void stream(const f32x4* __restrict__ a, const
     if (MODE == 1 && acc[0] == 123.456f) *sink = acc[1];
 }
 
+__global__ __launch_bounds__(512) void wgrad_shape(const f32x4* __restrict__ a, long np, int rows, float* sink) {
+    // workgroup = 256 consecutive rows x a range of 16-column stages; thread: row group tid >> 2 (x2 passes), column group tid & 3
+    const int tid = threadIdx.x;
+    const long nstage = np / 16;
+    const long s0 = nstage * blockIdx.x / gridDim.x, s1 = nstage * (blockIdx.x + 1) / gridDim.x;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int rb = 0; rb < rows; rb += 128) {
+        const int row = rb + (tid >> 2);
+        for (long st = s0; st < s1; ++st) {
+            const f32x4* p = a + (long)row * np + st * 16 + (tid & 3);
+            const f32x4 v0 = __builtin_nontemporal_load(p), v1 = __builtin_nontemporal_load(p + 4), v2 = __builtin_nontemporal_load(p + 8), v3 = __builtin_nontemporal_load(p + 12);
+            acc += v0 + v1 + v2 + v3;
+        }
+    }
+    if (acc[0] == 123.456f) *sink = acc[1];
+}
+
 template <int MODE, int SHAPE, int DEPTH>
 double run(const f32x4* a, const f32x4* b, f32x4* c, f32x4* d, long np, int rows, float* sink, int grid) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -75,13 +95,27 @@ double run(const f32x4* a, const f32x4* b, f32x4* c, f32x4* d, long np, int rows
     return bytes / (ms / reps * 1e-3) / 1e12;
 }
 
-int main() {
+int main(int argc, char** argv) {
     // one stash array of the 8x256 / 100 096-column step: [8 layers x 64 feature quads = 512 rows][np] granules = 0.82 GB
     const long np = 100096; const int rows = 512;
     const size_t bytes = (size_t)rows * np * 16;
     f32x4 *a, *b, *c, *d; float* sink;
     hipMalloc(&a, bytes); hipMalloc(&b, bytes); hipMalloc(&c, bytes); hipMalloc(&d, bytes); hipMalloc(&sink, 4);
     hipMemset(a, 0, bytes); hipMemset(b, 0, bytes);
+    if (argc > 1) {                                     // calibration run: one launch, known bytes
+        hipLaunchKernelGGL(wgrad_shape, dim3(256), dim3(512), 0, 0, a, np, rows, sink);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(wgrad_shape, dim3(256), dim3(512), 0, 0, a, np, rows, sink);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("wgrad-shaped read of %.0f bytes: %.2f TB/s\n", (double)bytes, bytes / (ms * 1e-3) / 1e12);
+        hipLaunchKernelGGL((stream<1, 1, 4>), dim3(256), dim3(512), 0, 0, a, b, c, d, np, rows, sink);
+        hipLaunchKernelGGL((stream<1, 0, 4>), dim3(256), dim3(512), 0, 0, a, b, c, d, np, rows, sink);
+        hipDeviceSynchronize();
+        return 0;
+    }
     printf("array %.2f GB each; TB/s (bytes read + written)\n", bytes / 1e9);
 #define ROW(M, name) \
     printf("%-28s linear d2 %.2f d4 %.2f d8 %.2f | stash-shaped d2 %.2f d4 %.2f d8 %.2f | 1024 WGs linear d4 %.2f\n", name, \
