@@ -249,8 +249,9 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
     peak_step = PEAK_F32_MFMA_TFLOPS if mult_step == 1 else PEAK_BF16_MFMA_TFLOPS
     step_tf = 6 * F0 * n_cols / (ms_step * 1e-3) / 1e12
     traffic, step_hbm, source = None, None, None
-    prof_json = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof_json) and points == 100000 and args.loss == "eikonal" and hidden == 256 and layers == 8:
+    # PMC bytes exist for the two workloads this file reports: the headline and config 3
+    prof_json = os.path.join(REPO, "profiles", {(256, 100000): "hbm_traffic.json", (512, 125000): "hbm_traffic_8x512.json"}.get((hidden, points), "-"))
+    if os.path.exists(prof_json) and args.loss == "eikonal" and layers == 8:
         try:                                        # PMC bytes were collected on exactly this workload, see `source`
             tr = json.load(open(prof_json))
             meta = tr.get("_meta", {})
@@ -270,7 +271,7 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
                             "note": "the stash (activations and adjoints kept between the four sweeps and the weight-gradient "
                                     "GEMM) is this dataflow's traffic; the step's inputs and outputs alone are 28 B per point + 4 B "
                                     "per parameter (SURVEY.md §8(d))"}
-            source = {"file": "profiles/hbm_traffic.json", "collected_by": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+            source = {"file": "profiles/" + os.path.basename(prof_json), "collected_by": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                       "passes over this bench (tools/pmc_passes.sh, profiles/summarize_pmc.py; FETCH_SIZE x2 per "
                       "MI355X_MICROARCH.md)", "summary": meta.get("summary"), "build": meta.get("build"),
                       "note": "counters cannot be read inside the timed run; these bytes belong to the build named here"}

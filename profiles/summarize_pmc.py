@@ -28,6 +28,10 @@ def kname(k):
     for f16 in ("sweep_f16_np_kernel", "sweep_f16_kernel"):             # the fp16x3 builds of the same sweeps (round 3)
         if f16 in k:
             k = k.replace(f16, "sweep_bf16_kernel")
+    for w in ("sweep_w16_kernel", "sweep_w_kernel"):                   # the 512-wide kernel: <SW, FL>
+        if w in k:
+            sig = k.split(w)[1].split("(")[0]
+            return {"<0, 3>": "sweep_fwd", "<1, 1>": "sweep_rev", "<2, 0>": "sweep_adj_fwd", "<3, 1>": "sweep_adj_rev"}.get(sig, "sweep_w" + sig)
     if "sweep_bf16_kernel" in k:
         sig = k.split("sweep_bf16_kernel")[1].split("(")[0]
         return NAMES.get(sig, "sweep" + sig)
@@ -45,6 +49,16 @@ def kname(k):
 def main():
     dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "pmc"
+    # --traffic <file>: where the per-launch bytes go (default: the headline workload's profiles/hbm_traffic.json);
+    # --workload <text>: what was profiled
+    tfile = sys.argv[sys.argv.index("--traffic") + 1] if "--traffic" in sys.argv else "hbm_traffic.json"
+    wl = (sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv
+          else "python bench.py --steps 3 --warmup 1 (8x256, 100 000 points, Eikonal loss_s1)")
+    skip = set()
+    for flag in ("--tag", "--traffic", "--workload"):
+        if flag in sys.argv:
+            skip.add(sys.argv[sys.argv.index(flag) + 1])
+    dirs = [a for a in dirs if a not in skip]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -76,9 +90,8 @@ def main():
         build = subprocess.check_output(["git", "-C", here, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         pass
-    traffic["_meta"] = {"summary": f"profiles/{tag}_pmc_summary.json", "build": build,
-                        "workload": "python bench.py --steps 3 --warmup 1 (8x256, 100 000 points, Eikonal loss_s1)"}
-    json.dump(traffic, open(os.path.join(here, "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    traffic["_meta"] = {"summary": f"profiles/{tag}_pmc_summary.json", "build": build, "workload": wl}
+    json.dump(traffic, open(os.path.join(here, tfile), "w"), indent=1, sort_keys=True)
     for k, m in out.items():
         print(k, {c: m[c] for c in ("duration_us", "clock_ghz", "hbm_read_bytes", "hbm_write_bytes") if c in m})
 

@@ -4,6 +4,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 SET=${1:-core}
+EXTRA=${2:-}                      # extra bench flags, e.g. "--hidden 512 --points 125000" (output dirs then carry the tag $3)
+TAGX=${3:-}
 if [ "$SET" = core ]; then
 CSETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
@@ -22,6 +24,6 @@ fi
 i=0
 for C in "${CSETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_${SET}_$i -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 > $R/gpurun_out/pmc_${SET}_$i.log 2>&1
-  grep -c . $R/gpurun_out/pmc_${SET}_$i/pmc_counter_collection.csv || grep -i 'unable' $R/gpurun_out/pmc_${SET}_$i.log | cut -c1-200
+  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_${SET}${TAGX}_$i -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 $EXTRA > $R/gpurun_out/pmc_${SET}${TAGX}_$i.log 2>&1
+  grep -c . $R/gpurun_out/pmc_${SET}${TAGX}_$i/pmc_counter_collection.csv || grep -i 'unable' $R/gpurun_out/pmc_${SET}${TAGX}_$i.log | cut -c1-200
 done
