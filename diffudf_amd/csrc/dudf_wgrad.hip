@@ -43,6 +43,7 @@ struct WgradArgs {
     int j0, nj;                         // hidden matrices [j0, j0 + nj) of this launch (matrix j = layer l = j + 2); grid.x = nj
     int Hs;                             // real layer width; the kernels' template H is the output TILE (<= 256):
                                         // blockIdx.z walks the (Hs/H)^2 tiles of a wider layer
+    int remap_nsplit;                   // > 0: 1-D grid, the output tiles of one (layer, column split) share an XCD (see the body)
     unsigned long long* clk;            // profiling: (shader clock, 100 MHz reference) ticks of workgroup (0,0,0), or nullptr
     const unsigned* amax;               // [4][L] bit patterns of max |q_l|, |A_l|, |zbar_l| over all columns (fp16x3 kernel)
 };
@@ -457,16 +458,25 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / W::WI, wi = wave % W::WI;
-    const int j = blockIdx.x + a.j0;
-    const int nsplit = gridDim.y;
+    // Layers wider than the tile (512: 2 x 2 tiles): the four tiles of one (layer, column split) read the same X rows twice
+    // and the same Y rows twice.  On a 1-D grid whose blocks are dealt round-robin over the 8 XCDs, blocks with equal id % 8
+    // share an XCD and its L2: a group's tiles get ids xcd + 8 * (4 * (group / 8) + tile), so the second reader of every row
+    // hits L2 instead of HBM (PMC r03_b: 15.2 GB fetched per launch at 8x512 / 125 000 points against 7.2 GB of operands).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nsplit = gridDim.y;
+    if (a.remap_nsplit > 0) {
+        const int id = blockIdx.x, slot = id >> 3, grp = (slot >> 2) * 8 + (id & 7);
+        if (grp >= a.nj * a.remap_nsplit) return;               // the grid is padded to whole XCD rounds
+        bz = slot & 3; bx = grp % a.nj; by = grp / a.nj; nsplit = a.remap_nsplit;
+    }
+    const int j = bx + a.j0;
     const int steps16 = a.steps_total * (KT / KB);
-    const int s0 = (int)((int64_t)steps16 * blockIdx.y / nsplit);
-    const int s1 = (int)((int64_t)steps16 * (blockIdx.y + 1) / nsplit);
+    const int s0 = (int)((int64_t)steps16 * by / nsplit);
+    const int s1 = (int)((int64_t)steps16 * (by + 1) / nsplit);
     const int tz = a.Hs / H;
-    const int o_off = (blockIdx.z / tz) * H, i_off = (blockIdx.z % tz) * H;
+    const int o_off = (bz / tz) * H, i_off = (bz % tz) * H;
     const int64_t xrow = (int64_t)(o_off / 4) * a.np * 4, yrow = (int64_t)(i_off / 4) * a.np * 4;
     // (fp16x3 build only: the bf16x6 build sits at 256 registers and four more live scalars make it spill)
-    const bool clk_on = SP != 0 && a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const bool clk_on = SP != 0 && a.clk != nullptr && bx == 0 && by == 0 && bz == 0;
     const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     f32x16 acc[W::MT][W::NTL];
@@ -817,7 +827,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         if (it + 2 < nit) stage(it + 2, Sc, std::false_type{}, B2{});
     }
 #if DUDF_WGRAD_DBG & 32
-    if (blockIdx.x == 3 && blockIdx.y == 10 && lane == 0)
+    if (bx == 3 && by == 10 && lane == 0)
         for (int i = 0; i < 12; ++i) g_wstamp[wave][i] = wst[i];
 #endif
 
@@ -995,7 +1005,15 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                         if (e != hipSuccess) return (int)e;
                         attr4 = true;
                     }
-                    hipLaunchKernelGGL((wgrad_hidden_f16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_h, st, a);
+                    static const bool xcd_remap = [] { const char* e = getenv("DUDF_WGRAD_XCD"); return !(e && e[0] == '0'); }();
+                    if (ntz == 4 && xcd_remap && !dudf_deterministic()) {          // 2 x 2 tiles: a group's tiles on one XCD
+                        WgradArgs b = a;
+                        b.remap_nsplit = nsplit;
+                        const int groups = nl * nsplit, grid1 = ((groups + 7) / 8) * 32;
+                        hipLaunchKernelGGL((wgrad_hidden_f16p_kernel<H, 9>), dim3(grid1), dim3(NTHR), smem_h, st, b);
+                    } else {
+                        hipLaunchKernelGGL((wgrad_hidden_f16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_h, st, a);
+                    }
                     return (int)hipGetLastError();
                 }
                 if (!attr3) {
@@ -1040,6 +1058,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.have_g = have_g; a.Hs = lo.H;
     a.amax = reinterpret_cast<const unsigned*>(ws + lo.ws_amax);
     a.clk = dudf_prof_clk(PROF_WGRAD_HIDDEN);
+    a.remap_nsplit = 0;
     const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
     a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;
