@@ -243,8 +243,9 @@ def test_unsupported_configs_fail_loudly(hip):
 
 
 def test_f32_and_bf16x6_sweeps_agree():
-    """The 256-wide plain path runs its hidden matmuls on the bf16 cores (exact 3-way split, csrc/dudf_sweep_bf16.hip);
-    DUDF_SWEEP=f32 / DUDF_WGRAD=f32 select the f32-input MFMA kernels.  Both must meet the SAME oracle tolerances, and
+    """The 256-wide plain path runs its hidden matmuls on the 16-bit matrix cores — fp16 hi/lo split, three products
+    (default since round 3) or the exact 3-way bf16 split, six products (DUDF_SPLIT=bf16; csrc/dudf_sweep_bf16.hip) —;
+    DUDF_SWEEP=f32 / DUDF_WGRAD=f32 select the f32-input MFMA kernels.  All three must meet the SAME oracle tolerances, and
     agree with each other far inside them (the env is read once per process, hence the child process)."""
     import subprocess
     import sys
@@ -266,7 +267,7 @@ np.savez(sys.argv[1], terms=terms.cpu().numpy(), g=g.cpu().numpy(), f=f.cpu().nu
     import tempfile
     outs = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, env in (("bf16", {}), ("f32", {"DUDF_SWEEP": "f32", "DUDF_WGRAD": "f32"})):
+        for tag, env in (("fp16", {}), ("bf16", {"DUDF_SPLIT": "bf16"}), ("f32", {"DUDF_SWEEP": "f32", "DUDF_WGRAD": "f32"})):
             path = os.path.join(td, tag + ".npz")
             e = dict(os.environ); e.update(env)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=600)
@@ -276,13 +277,46 @@ np.savez(sys.argv[1], terms=terms.cpu().numpy(), g=g.cpu().numpy(), f=f.cpu().nu
     terms, grads, dbg = O.loss_and_grad("s1", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64),
                                         [1e4, 1e4, 0.0, 1e3], 100.0)
     gref = np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
-    for tag in ("bf16", "f32"):
+    for tag in ("fp16", "bf16", "f32"):
         assert rel(outs[tag]["f"], dbg["y"]) < 5e-6, tag
         assert rel(outs[tag]["gr"], dbg["g"]) < 2e-5, tag
         assert rel(outs[tag]["g"], gref) < 1e-4, tag
         assert rel(outs[tag]["terms"], np.array(list(terms.values()))) < 1e-5, tag
     assert rel(outs["bf16"]["f"], outs["f32"]["f"]) < 2e-6
     assert rel(outs["bf16"]["g"], outs["f32"]["g"]) < 5e-6
+    assert rel(outs["fp16"]["f"], outs["f32"]["f"]) < 2.5e-6          # fp16x3 vs f32: the same bars (+ the 2^-23 worst-case piece)
+    assert rel(outs["fp16"]["gr"], outs["f32"]["gr"]) < 5e-6
+    assert rel(outs["fp16"]["g"], outs["f32"]["g"]) < 5e-6
+    assert rel(outs["fp16"]["g"], outs["bf16"]["g"]) < 5e-6
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1e-4, 1.0, 1e6, 1e12])
+def test_fp16x3_range_scaling(hip, scale):
+    """fp16x3 buys fp16's range with powers of two: per matrix (weights), per column (the sweeps' B operands), per layer
+    (the weight-gradient GEMM's operands).  The backward is linear in the upstream cotangent, so scaling `cot` by 1e-12 ...
+    1e12 moves every adjoint quantity (A_l, e_l, zbar_l) across 24 decades — far outside fp16 — and d(theta) must simply
+    scale with it; a network whose hidden weights are 4x larger / 64x smaller than SIREN's init exercises the weight scale
+    (much larger weights push the sine arguments to hundreds of radians, where fp32 itself — the reference's too — is off)."""
+    hidden, n = [256] * 4, 700
+    P, theta, x, nrm, sdf = setup(hidden, n, 21)
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda")
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, ws)
+    g1 = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.ones(4, device="cuda"), None, ws).clone()
+    gs = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.full((4,), scale, device="cuda"), None, ws)
+    assert torch.isfinite(gs).all()
+    assert rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy()) < 2e-6, scale
+    if scale in (1e-4, 1e6):                             # weights far from the init's size: oracle-direct
+        k = 4.0 if scale > 1 else 1.0 / 64.0
+        P2 = [(w * (k if 0 < i < len(P) - 1 else 1.0), b) for i, (w, b) in enumerate(P)]
+        th2 = dev(np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in P2]).astype(np.float32))
+        P2 = [(w.astype(np.float32).astype(np.float64), b) for w, b in P2]
+        terms = hip.loss_forward(cfg, hip.LOSS_S1, th2, xd, nd, sd, n, W_S1EIK, 100.0, ws)
+        g2 = hip.loss_backward(cfg, hip.LOSS_S1, th2, xd, nd, sd, n, W_S1EIK, 100.0, torch.ones(4, device="cuda"), None, ws)
+        t_ref, g_ref, _ = O.loss_and_grad("s1", P2, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), W_S1EIK, 100.0)
+        assert rel(terms.cpu().numpy(), np.array([float(v) for v in t_ref.values()])) < 1e-5, k
+        assert rel(g2.cpu().numpy(), flat(g_ref)) < (1e-4 if k < 1 else 3e-4), k
 
 
 def test_deterministic_mode_is_bit_reproducible():

@@ -87,6 +87,20 @@ def test_sharded_hip_step_equals_single_rank(tmp_path, case):
         assert e_h.max() < (5e-2 if case == "s1full" else 1e-4)
 
 
+def test_fused_and_staggered_collectives_agree(tmp_path, monkeypatch):
+    """`TrainEngine(collectives=...)` / DUDF_COLLECTIVES: ONE all-reduce of the flat [dtheta | terms] buffer after the whole
+    backward ("fused") and the five staggered ones behind the weight-gradient groups (default) are two schedules of the
+    same sum — same loss curve, same theta (round 3: both exist so that the first hardware multi-GPU run can time them)."""
+    res = {}
+    for mode in ("staggered", "fused"):
+        monkeypatch.setenv("DUDF_COLLECTIVES", mode)
+        out = str(tmp_path / f"{mode}.npz")
+        _launch(2, ["engine", "s1eik", out])
+        res[mode] = np.load(out)
+    a, b = res["staggered"], res["fused"]
+    assert rel(b["hist"], a["hist"]) < 2e-6 and rel(b["dtheta0"], a["dtheta0"]) < 2e-5 and rel(b["theta"], a["theta"]) < 1e-3
+
+
 def test_train_py_two_ranks_cover_both_stages(tmp_path):
     """train.py's own distributed path (_zero_flat_grad / _allreduce_step, dudf_n_global, the s2 statistics all-reduce)
     over an s1 -> s2 schedule: the 2-rank losses.csv must equal the 1-rank one — in particular the stage-2 rows, whose
