@@ -203,7 +203,7 @@ int backward_sweeps(Ctx& c, const float* theta, int have_g, bool zeroed) {
 extern "C" {
 
 const char* dudf_version(void) {
-    return "dudf_hip 0.3 (gfx950: bf16x6 MFMA sweeps and weight-gradient GEMM at fp32 accuracy, f32-input MFMA variants, "
+    return "dudf_hip 0.4 (gfx950: fp16x3 / bf16x6 MFMA sweeps and weight-gradient GEMM at fp32 accuracy, f32-input MFMA variants, "
            "Hessian quads, third-order jets, GPU sampler, ray marching)";
 }
 
