@@ -959,7 +959,11 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     const int nl = a.nj;
     if (nl <= 0) return 0;
     const int tz = a.Hs / H, ntz = tz * tz;              // output tiles of a layer wider than the 256 x 256 tile
-    int nsplit = 256 / (nl * ntz);                       // one resident workgroup per CU, a single round
+    // one resident workgroup per CU, a single round.  DUDF_WGRAD_MAXWG (default 256) caps the grid: with more than one rank
+    // the engine sets 240, so that an RCCL kernel queued behind the previous layer group finds free CUs beside this GEMM
+    // (its workgroups fill the register file of the CUs they run on)
+    static const int maxwg = [] { const char* e = getenv("DUDF_WGRAD_MAXWG"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v : 256; }();
+    int nsplit = maxwg / (nl * ntz);
     if (nsplit > a.steps_total) nsplit = a.steps_total;
     if (nsplit < 1 || dudf_deterministic()) nsplit = 1;      // deterministic: one workgroup per weight tile, one add per element
     static bool attr_done = false;

@@ -60,6 +60,10 @@ class TrainEngine:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
+        if self.world > 1 and self.collectives == "staggered":
+            # leave 16 CUs to the RCCL kernels that overlap the weight-gradient GEMMs (read once by the library, at its
+            # first launch; a caller's own setting wins)
+            os.environ.setdefault("DUDF_WGRAD_MAXWG", "240")
 
     def _allreduce(self, t):
         if self.world > 1:
