@@ -159,6 +159,7 @@ class Runner:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             el, med = float(t[0]), float(t[1])
         info = {"median_ms": med, "min_ms": per_step[0], "max_ms": per_step[-1], "kern": {}, "clocks_mhz": {}, "phases_ms": None,
+                "event_cost_per_launch_ms": None,
                 "event_pair_overhead_ms": None, "profiled_step_ms": None, "collectives": getattr(eng, "collectives", None)}
         if profile_steps:
             # what an empty event pair reads on this stream: subtracted from every per-kernel duration (round 2: the raw
@@ -181,15 +182,26 @@ class Runner:
             eng.profile = False
             buf = ctypes.create_string_buffer(4096)
             self.lib.dudf_profile_dump(buf, len(buf))
+            raw, launches = {}, 0
             for line in buf.value.decode().splitlines():
                 name, cnt, tot = line.split()
-                info["kern"][name] = max(float(tot) / int(cnt) - ov, 0.0)
+                raw[name] = float(tot) / int(cnt)
+                launches += int(cnt)
+            # what bracketing a launch with two events costs: an empty pair reads `ov`, but the events also serialise the
+            # stream — the profiled steps are slower than the timed ones by (profiled - timed) spread over the launches of a
+            # step.  The larger of the two is taken off every kernel's duration (so that the kernels of a step add up to at
+            # most the step they are part of; rocprofv3's own averages are in profiles/)
+            prof_step = sorted(pm[i].elapsed_time(pm[i + 1]) for i in range(profile_steps))[profile_steps // 2]
+            per_launch = max(ov, (prof_step - med) / max(launches / profile_steps, 1.0)) if self.world == 1 else ov
+            for name, v in raw.items():
+                info["kern"][name] = max(v - per_launch, 0.0)
+            info["event_cost_per_launch_ms"] = per_launch
             self.lib.dudf_profile_clocks(buf, len(buf))
             for line in buf.value.decode().splitlines():
                 name, mhz = line.split()
                 info["clocks_mhz"][name] = float(mhz)
             info["event_pair_overhead_ms"] = ov
-            info["profiled_step_ms"] = sorted(pm[i].elapsed_time(pm[i + 1]) for i in range(profile_steps))[profile_steps // 2]
+            info["profiled_step_ms"] = prof_step
             if self.world > 1:
                 info["phases_ms"] = {k: round(v, 4) for k, v in eng.phase_times().items()}
         del eng
@@ -297,10 +309,11 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
                 "all_mfma_kernels": per, "step_hbm": step_hbm,
                 "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k not in alg},
                 "kernel_times_sum_ms": round(sum(kern.values()), 4), "profiled_step_ms": info["profiled_step_ms"],
-                "event_pair_overhead_ms": info["event_pair_overhead_ms"],
+                "event_pair_overhead_ms": info["event_pair_overhead_ms"], "event_cost_per_launch_ms": info["event_cost_per_launch_ms"],
                 "kernel_times_from": f"untimed pass of {PROFILE_STEPS} steps with HIP events on the launch stream (dudf_profile_*), "
-                                     "minus the duration an empty event pair reads on the same stream; clock_mhz = shader clock "
-                                     "over the lifetime of the kernel's first workgroup (s_memtime / s_memrealtime)"})
+                                     "minus event_cost_per_launch_ms = max(what an empty event pair reads, (profiled step - timed "
+                                     "step) / launches per step); clock_mhz = shader clock over the lifetime of the kernel's first "
+                                     "workgroup (s_memtime / s_memrealtime)"})
     return out
 
 

@@ -43,6 +43,9 @@
 #ifndef DUDF_HI_DMA
 #define DUDF_HI_DMA 0                        // partial passes: the idle half issues the DMA pieces (measured: no gain)
 #endif
+#ifndef DUDF_OCT
+#define DUDF_OCT 1                           // a pass with a single 16-column group is shared by all eight waves (sweep_tile_oct)
+#endif
 #ifndef DUDF_TSPLIT
 #define DUDF_TSPLIT 0
 #endif
@@ -671,6 +674,211 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     }
 }
 
+// ---- "oct mode": a pass that holds ONE 16-column group (the last pass of a workgroup's share: at 100 000 points 112 of the 256
+// workgroups end with one) ---------------------------------------------------------------------------------------------------
+// With sweep_tile_b a lone wave does everything serially: 8 tails and 8 x 48 MFMAs per layer, nothing to overlap them with
+// (measured in situ: 0.19 ms of a 3.2 ms step; alone, a lone-wave pass takes 0.68 of a full one).  Here all eight waves share
+// the group: wave w owns output tiles 2w, 2w+1 — exactly the pair whose post-tail values are the B operand of k-block w of
+// the next matrix.  Per layer: [column scale: max over the waves' 32 features each, through LDS] -> every wave runs ONE
+// tail pair (in parallel: an eighth of the lone wave's tail work) and publishes its B fragment (hi | lo, 2 KiB) in LDS ->
+// 8 k-blocks of 6 MFMAs per wave, B(kb) read from LDS.  fp16x3, plain columns, H = 256.  No weight chunks through LDS here: a
+// wave needs only ITS two tiles' fragments (4 KiB of a 32 KiB chunk), so it loads them from L2 straight into registers — all
+// 32 fragments of a layer at the top of the layer, behind the exchange and the tail (a step of 6 MFMAs is far shorter than
+// an LDS-DMA round trip: with the chunk stream the pass was bound by DMA latency).  Two barriers per layer, no hand-counted
+// waits; the chunk buffers and `gc` are left alone.
+constexpr int kOctBytes = 8 * 2 * 1024 + 1024 + 8 * 64 * 16;      // B fragments | column maxima (2 x 128 floats) | output-stage partials
+template <int H, int SW, int FL>
+__device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, char* lds, unsigned& gc, const unsigned oct_off) {
+    using G = GeoB<H, 1>;
+    static_assert(H == 256 && SW <= SWEEP_ADJ_REV, "fp16x3, plain columns, one k-block per wave");
+    constexpr int NPC = 2;
+    constexpr int BS = base_of(SW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int nhid = a.L - 1;
+    constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
+    constexpr bool kColScale = BS != SWEEP_FWD;
+    constexpr bool kTrackE = BS == SWEEP_ADJ_FWD;
+    constexpr int kRow = amax_row<SW, FL>();
+    const int64_t p = (int64_t)g * 16 + li;
+    const int T0 = 2 * wave;
+    auto image = [&](int j) -> const char* {
+        return kFwdDir ? a.wimg16_f + (size_t)j * G::IMGB : a.wimg16_t + (size_t)(nhid - 1 - j) * G::IMGB;
+    };
+    auto unscale_of = [&](int j) -> float { return a.wsc[kFwdDir ? j : nhid - 1 - j]; };
+    auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
+    auto stash_base = [&](int layer, int T) -> int64_t {
+        const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);
+    char* ox = lds + oct_off;
+    u32x4* Bx = reinterpret_cast<u32x4*>(ox);                          // [k-block][piece][lane]
+    float* cmx = reinterpret_cast<float*>(ox + 8 * NPC * 1024);        // [wave][column]: max |accumulator|
+    float* emx = cmx + 128;                                            // [wave][column]: max |e_l| (adjoint forward sweep)
+    f32x4* red = reinterpret_cast<f32x4*>(ox + 8 * NPC * 1024 + 1024); // [wave][lane]: output-stage partial sums
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
+
+    (void)gc;
+    __syncthreads();                                   // every wave is past its last LDS read of the previous pass
+
+    // first layer (fp32, K = 3): my two tiles
+    f32x4 prev[2], acc[2];
+    {
+        float b = 0.f, yb = 1.f;
+        if constexpr (BS == SWEEP_FWD) b = (q < 3) ? a.x4[p * 4 + q] : 0.f;
+        if constexpr (BS == SWEEP_ADJ_FWD) b = (q < 3) ? a.gbar[p * 4 + q] : 0.f;
+        if constexpr (BS == SWEEP_ADJ_REV) yb = a.ybar[p];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int T = T0 + u;
+            if constexpr (kFwdDir) prev[u] = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
+            else prev[u] = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
+        }
+    }
+    f32x4 o1[2], o2[2], o3[2], bs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto load_ops = [&](int layer) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            epilogue_loads<SW, FL>(a, stash_base(layer, T0 + u), vo, o1[u], o2[u], o3[u]);
+            if constexpr (BS == SWEEP_FWD)
+                bs[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + 3 * G::CHUNKB) + layer * H + 16 * (T0 + u) + 4 * q);
+        }
+    };
+    auto ebound_of = [&](int layer) -> float {
+        if constexpr (BS == SWEEP_ADJ_REV && (FL & 1) != 0) return a.ebound[(int64_t)layer * a.np + p];
+        return 0.f;
+    };
+    load_ops(in_layer(0));
+    float eb = ebound_of(in_layer(0));
+    float unscale = 1.f, sb = 1.f, inv_sb = 1.f;
+    TailTrack tk;
+    f32x4 e[2];
+    for (int j = 0; j <= nhid; ++j) {
+        const int lin = in_layer(j);
+        if constexpr (kColScale) {                      // the column's scale from ALL 16 tiles: max over the eight waves
+            float m = 0.f;
+            dudf_track(m, prev[0]); dudf_track(m, prev[1]);
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (q == 0) cmx[wave * 16 + li] = m;
+            __syncthreads();
+            float mm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) mm = fmaxf(mm, cmx[w * 16 + li]);
+            const float bound = a.w0 * (mm * unscale) + eb;
+            unsigned E = (__float_as_uint(bound) >> 23) & 255u;
+            E = E < 27u ? 27u : (E > 250u ? 250u : E);
+            sb = __uint_as_float((268u - E) << 23);
+            inv_sb = __uint_as_float((E - 14u) << 23);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                   // ONE tail pair per wave and layer
+            f32x4 z = prev[u];
+            if constexpr (BS == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[u]);
+            else z *= unscale;
+            e[u] = epilogue<SW, FL, kTrackE>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
+        }
+        if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) atomicMax(lds_amax + lin, __float_as_uint(tk.t)); tk.t = 0.f; }
+        if constexpr (kTrackE) {
+            float m = fmaxf(tk.e, __shfl_xor(tk.e, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (q == 0) emx[wave * 16 + li] = m;
+            tk.e = 0.f;
+        }
+        if (j == nhid) break;
+        // this wave's A fragments of matrix j: [k-block][tile][piece], 16 B per lane each
+        u32x4 fr[G::NKB][2][NPC];
+        {
+            const char* img = image(j) + (size_t)lane * 16;
+#pragma unroll
+            for (int kb = 0; kb < G::NKB; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc)
+                        fr[kb][u][pc] = *reinterpret_cast<const u32x4*>(img + (size_t)kb * G::CHUNKB + ((T0 + u) * NPC + pc) * G::FRAG);
+        }
+        u32x4 bh, bl;
+        if constexpr (kColScale) split8h(e[0] * sb, e[1] * sb, bh, bl);
+        else split8h(e[0], e[1], bh, bl);
+        Bx[(wave * NPC + 0) * 64 + lane] = bh;          // = the B operand of k-block `wave` of matrix j
+        Bx[(wave * NPC + 1) * 64 + lane] = bl;
+        load_ops(in_layer(j + 1));                      // the next layer's tail operands: a whole k-loop ahead
+        eb = ebound_of(in_layer(j + 1));
+        __syncthreads();
+        if constexpr (kTrackE) {                        // per layer and column max_f |e_l| for the adjoint reverse sweep
+            if (wave == 0 && q == 0 && a.ebound) {
+                float m = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWB; ++w) m = fmaxf(m, emx[w * 16 + li]);
+                a.ebound[(int64_t)lin * a.np + p] = m;
+            }
+        }
+        acc[0] = f32x4{0, 0, 0, 0}; acc[1] = acc[0];
+#pragma unroll
+        for (int kb = 0; kb < G::NKB; ++kb) {
+            const u32x4 b0 = Bx[(kb * NPC + 0) * 64 + lane], b1 = Bx[(kb * NPC + 1) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 cc = acc[u];
+                cc = mfma_h(as_h(fr[kb][u][1]), as_h(b0), cc);    // smallest terms first: lo*hi, hi*lo, hi*hi
+                cc = mfma_h(as_h(fr[kb][u][0]), as_h(b1), cc);
+                cc = mfma_h(as_h(fr[kb][u][0]), as_h(b0), cc);
+                acc[u] = cc;
+            }
+        }
+        __syncthreads();                                // every wave has read B: the next layer may overwrite it
+        prev[0] = acc[0]; prev[1] = acc[1];
+        unscale = kColScale ? unscale_of(j) * inv_sb : unscale_of(j);
+    }
+    // output stage: the eight waves' partial results through LDS
+    if constexpr (BS == SWEEP_FWD) {
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * (T0 + u) + 4 * q);
+            part += e[u][0] * wv[0] + e[u][1] * wv[1] + e[u][2] * wv[2] + e[u][3] * wv[3];
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (q == 0) cmx[wave * 16 + li] = part;
+        __syncthreads();
+        if (wave == 0 && q == 0) {
+            float y = a.theta[a.off_bo];
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) y += cmx[w * 16 + li];
+            a.y[p] = y;
+        }
+    } else if constexpr (BS == SWEEP_REV) {
+        f32x4 accg = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w1t16 + li * H + 16 * (T0 + u) + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accg = mfma16(wv[t], e[u][t], accg);
+        }
+        red[wave * 64 + lane] = accg;
+        __syncthreads();
+        if (wave == 0 && q == 0) {
+            f32x4 sum = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) sum += red[w * 64 + lane];
+            *reinterpret_cast<f32x4*>(a.g + p * 4) = f32x4{sum[0], sum[1], sum[2], 0.f};
+        }
+    } else if constexpr (kTrackE) {                     // the last layer's max |e_l|
+        __syncthreads();
+        if (wave == 0 && q == 0 && a.ebound) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) m = fmaxf(m, emx[w * 16 + li]);
+            a.ebound[(int64_t)in_layer(nhid) * a.np + p] = m;
+        }
+    }
+}
+
 template <int H, int SW, int FL, int SP = 0>
 __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
@@ -696,8 +904,17 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     // a pass with one wave per SIMD (or a single wave) costs about half a full one, a whole extra round would cost all of it
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
-    for (int g = g0; g < g1; g += NWB)
+    constexpr bool kOct = DUDF_OCT && SP != 0 && H == 256 && SW <= SWEEP_ADJ_REV;
+    for (int g = g0; g < g1; g += NWB) {
+        if constexpr (kOct) {
+            if (g1 - g == 1) {                          // a pass with one group: all eight waves share it
+                const unsigned oct_off = 3 * GeoB<H, SP>::CHUNKB + (base_of(SW) == SWEEP_FWD ? (unsigned)(a.L * H * sizeof(float)) : (unsigned)(kMaxAmaxLayers * sizeof(unsigned)));
+                sweep_tile_oct<H, SW, FL>(a, gbase + g, lds_b, gc, oct_off);
+                continue;
+            }
+        }
         sweep_tile_b<H, SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && blockIdx.x == 100 && g == g0);
+    }
     if constexpr (kRow >= 0) {
         __syncthreads();
         if ((int)threadIdx.x < a.L && (int)threadIdx.x < kMaxAmaxLayers && a.amax) {
@@ -926,9 +1143,10 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     // fp16x3 (DUDF_SPLIT, DUDF_SPLIT_SWEEPS): the plain columns' four sweeps
     if (which <= SWEEP_ADJ_REV && ((a.split >> which) & 1)) {
         constexpr size_t w3 = 3 * GeoB<H, 1>::CHUNKB;
-        const size_t smem_f = w3 + (size_t)a.L * H * sizeof(float);          // + the biases (forward sweep)
-        constexpr size_t smem_fmax = w3 + kMaxLdsBiasLayers * H * sizeof(float);
-        constexpr size_t smem_o = w3 + kMaxAmaxLayers * sizeof(unsigned);    // + the per-layer running maxima
+        constexpr size_t oct = (H == 256) ? kOctBytes : 0;                   // + the exchange area of the one-group pass
+        const size_t smem_f = w3 + (size_t)a.L * H * sizeof(float) + oct;    // + the biases (forward sweep)
+        constexpr size_t smem_fmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + oct;
+        constexpr size_t smem_o = w3 + kMaxAmaxLayers * sizeof(unsigned) + oct;   // + the per-layer running maxima
         bool done = true;
         if (which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {
             if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3, sweep_f16_np_kernel, smem_fmax, smem_f);

@@ -207,5 +207,18 @@ def analyse_f16(asm_path, width=256):
                     waits.append((n, late, slack))
                 fifo = young
                 epoch += 1
-        out[(int(m.group(2)), int(m.group(3)))] = {"waits": waits, "scratch": scratch}
+        # spills INSIDE a block that multiplies (the hand-counted k-block steps) would sit in the vmcnt queue between the DMA
+        # pieces; a long-lived scalar parked once at kernel entry and fetched at its exit does not
+        hot, cur, cur_mfma = 0, 0, False
+        for ln in body.split("\n") + [".LBB_end:"]:
+            t = ln.strip()
+            if re.match(r"^\.LBB", t):
+                if cur_mfma:
+                    hot += cur
+                cur, cur_mfma = 0, False
+            elif t.startswith("scratch_"):
+                cur += 1
+            elif t.startswith("v_mfma"):
+                cur_mfma = True
+        out[(int(m.group(2)), int(m.group(3)))] = {"waits": waits, "scratch": scratch, "scratch_hot": hot}
     return out

@@ -94,6 +94,12 @@ def test_step_against_oracle_at_full_size(hidden, n):
     rng = np.random.default_rng(5)
     starts = np.arange(0, n, 128)
     idx = np.minimum(starts + rng.integers(0, 128, starts.size), n - 1)
+    # ... plus every column of a few ONE-group passes (a workgroup's share of 16-column groups is walked in passes of 8; the
+    # last pass of 112 workgroups holds a single group at 100 000 points, which all eight waves then share: "oct mode")
+    ng = (n + 127) // 128 * 8
+    lone = [b for b in range(256) if ((b + 1) * ng // 256 - b * ng // 256) % 8 == 1][:3]
+    extra = np.concatenate([np.arange(16) + 16 * ((b + 1) * ng // 256 - 1) for b in lone]) if lone else np.zeros(0, int)
+    idx = np.unique(np.concatenate([idx, extra[extra < n]])).astype(np.int64)
     L = len(hidden)
     got = {}
     for name in ("s", "c", "q", "A", "e", "zbar"):
