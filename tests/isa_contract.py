@@ -111,7 +111,8 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
         m = re.search(r"^(_ZN\w*wgrad_hidden_bf16q_kernelILi256E\w*):", txt, re.M)
     else:
         m = re.search(r"^(_ZN\w*wgrad_hidden_bf16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
-    body = txt[m.end():txt.index("s_endpgm", m.end())].split("\n")
+    # (to the end of the FUNCTION, not to the first s_endpgm: the kernel returns early for the padding blocks of its 1-D grid)
+    body = txt[m.end():re.compile(r"^\.Lfunc_end\d+:", re.M).search(txt, m.end()).start()].split("\n")
     blocks, cur, name = [], [], "entry"
     for ln in body:
         t = ln.strip()
