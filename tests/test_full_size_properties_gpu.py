@@ -43,12 +43,19 @@ def test_query_is_per_point_at_full_size():
     hip, cfg, P, th, x, nrm, sdf = _setup([256] * 8, 100000, 123)
     f, g = hip.query(cfg, th, x)
     idx = np.random.default_rng(0).choice(100000, 256, replace=False)
+    # + every column of three one-group passes (the last pass of a workgroup that holds 25 groups: all eight waves share it)
+    ng = (100000 + 127) // 128 * 8
+    lone = [b for b in range(256) if ((b + 1) * ng // 256 - b * ng // 256) % 8 == 1][:3]
+    extra = np.concatenate([np.arange(16) + 16 * ((b + 1) * ng // 256 - 1) for b in lone])
+    idx = np.unique(np.concatenate([idx, extra[extra < 100000]]))
     P64 = [(a.astype(np.float64), b.astype(np.float64)) for a, b in P]
     yo, cache = O.forward(P64, x[idx].double().cpu().numpy())
     go = O.input_gradient(P64, cache)[0]
     assert rel(f[idx].cpu().numpy(), yo) < 5e-6
     assert rel(g[idx].cpu().numpy(), go) < 2e-5
     # the same points queried alone give the same numbers (no dependence on the batch they travel in)
+    f0, _ = hip.query(cfg, th, x, want_grad=False)                   # the value-only variant of the forward sweep
+    assert rel(f0[idx].cpu().numpy(), yo) < 5e-6
     f2, g2 = hip.query(cfg, th, x[idx].contiguous())
     assert rel(f2.cpu().numpy(), f[idx].cpu().numpy()) < 1e-6 and rel(g2.cpu().numpy(), g[idx].cpu().numpy()) < 1e-6
 
