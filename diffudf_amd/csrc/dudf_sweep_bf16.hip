@@ -253,6 +253,12 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     float sb = 1.f, inv_sb = 1.f;                       // scale of the B operand being built (tails of `prev`) and its inverse
     auto colmax = [&](const f32x4 (&t)[G::NT]) -> float {      // max |.| over the 16 tiles' registers and the 4 lane quarters: per column
         float m = 0.f;
+        // dudf_track is inline asm, and these are MFMA results: hipcc's hazard recogniser does not see an asm statement's
+        // register reads, so the wait states between the last MFMA and the first read are spelled out (found the hard way:
+        // the last layer's column scale came from stale accumulators)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int T = 0; T < G::NT; ++T) dudf_track(m, t[T]);
         m = fmaxf(m, __shfl_xor(m, 16));
@@ -760,6 +766,9 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
         const int lin = in_layer(j);
         if constexpr (kColScale) {                      // the column's scale from ALL 16 tiles: max over the eight waves
             float m = 0.f;
+            __builtin_amdgcn_sched_barrier(0);          // MFMA results read by inline asm: explicit wait states (see colmax)
+            asm volatile("s_nop 15\n\ts_nop 15");
+            __builtin_amdgcn_sched_barrier(0);
             dudf_track(m, prev[0]); dudf_track(m, prev[1]);
             m = fmaxf(m, __shfl_xor(m, 16));
             m = fmaxf(m, __shfl_xor(m, 32));

@@ -144,7 +144,10 @@ constexpr int amax_row() {
 }
 struct TailTrack { float t = 0.f, e = 0.f; };          // running max |.| of the wgrad operand a tail stores | of e_l (adjoint forward sweep)
 __device__ __forceinline__ void dudf_track(float& tmax, const f32x4 v) {
-    tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    // two v_max3_f32 with |.| source modifiers (fmaxf() would add IEEE canonicalisation instructions around every maximum:
+    // +12 vector-ALU instructions per k-block step in the stash-bound sweeps)
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(tmax) : "v"(v[0]), "v"(v[1]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(tmax) : "v"(v[2]), "v"(v[3]));
 }
 
 template <int SW, int FL, bool TE = false>
