@@ -68,6 +68,13 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// one LDS atomic per wave: 64 lanes hitting the same LDS word serialise (measured: the per-layer publish of the quads' forward
+// sweep cost 0.09 ms per launch that way), so the wave reduces first
+__device__ __forceinline__ void lds_max_wave(unsigned* word, float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(v));
+}
 constexpr int kMaxAmaxLayers = 64;                     // LDS words of the per-layer running maxima (deeper nets: no fp16x3 wgrad)
 constexpr int NWB = 8;                                 // waves per workgroup: two per SIMD
 constexpr int TILEB = NWB * 16;                        // columns per workgroup pass
@@ -282,7 +289,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     TailTrack tmax;
     unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
     auto publish = [&](int layer) {
-        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax.t)); tmax.t = 0.f; }
+#ifdef DUDF_DBG_NOPUBLISH
+        if constexpr (kRow >= 0) { asm volatile("" :: "v"(tmax.t)); tmax.t = 0.f; }
+#else
+        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) lds_max_wave(lds_amax + layer, tmax.t); tmax.t = 0.f; }
+#endif
     };
     // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
@@ -790,7 +801,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
             else z *= unscale;
             e[u] = epilogue<SW, FL, kTrackE>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
         }
-        if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) atomicMax(lds_amax + lin, __float_as_uint(tk.t)); tk.t = 0.f; }
+        if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) lds_max_wave(lds_amax + lin, tk.t); tk.t = 0.f; }
         if constexpr (kTrackE) {
             float m = fmaxf(tk.e, __shfl_xor(tk.e, 16));
             m = fmaxf(m, __shfl_xor(m, 32));
@@ -1358,7 +1369,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             }
             acc[T] = f32x4{0, 0, 0, 0};
         }
-        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) atomicMax(lds_amax + layer, __float_as_uint(tmax.t)); }
+        if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) lds_max_wave(lds_amax + layer, tmax.t); }
         if constexpr (kColScale) {                     // the next layer's B operand = these outputs: scale the column below 2^15
             cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
             cmax = fmaxf(cmax, __shfl_xor(cmax, 32));

@@ -137,6 +137,9 @@ __constant__ unsigned kJetLane[16] = {
 // maximum of what they store (2 v_max3_f32 per tile), published per layer through LDS and once per workgroup to HBM.
 template <int SW, int FL>
 constexpr int amax_row() {
+#ifdef DUDF_DBG_NOTRACK_H                        // timing experiment only (wrong weight-gradient scales): no running maxima in the quad sweeps
+    if (SW >= 4) return -1;
+#endif
     return SW == SWEEP_FWD_H ? ((FL & 1) ? 3 : -1)      // h | hdot^k: the tangent channels are not bounded by 1 (plain columns: |h| <= 1)
          : (base_of(SW) == SWEEP_REV && SW != SWEEP_FWD_J) ? ((FL & 1) ? 0 : -1)
          : base_of(SW) == SWEEP_ADJ_FWD ? 1
