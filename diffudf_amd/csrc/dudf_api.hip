@@ -64,7 +64,7 @@ bool use_bf16_sweeps() {
 }
 
 int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
-    if (!ws || bytes < lo.total_bytes || (reinterpret_cast<uintptr_t>(ws) & 15)) return DUDF_E_WORKSPACE;
+    if (!ws || bytes < lo.total_bytes || (reinterpret_cast<uintptr_t>(ws) & 255)) return DUDF_E_WORKSPACE;
     if (lo.np > (1ll << 25)) return DUDF_E_BADCFG;          // 32-bit lane BYTE offsets inside a stash layer (4 np granules of 16 B)
     return 0;
 }
@@ -284,7 +284,7 @@ int make_curv_layout(const dudf_net_cfg* cfg, int64_t n, CurvLayout* cl) {
     if (cl->npj == 0) cl->npj = DUDF_TILE_PTS;
     if (cl->npj > (1ll << 25)) return DUDF_E_BADCFG;
     int64_t o = (int64_t)(cl->q.total_bytes / sizeof(float));
-    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) / 4 * 4; return r; };
+    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64; return r; };
     cl->o_lam = take(3 * n); cl->o_V = take(9 * n); cl->o_x4 = take(4 * cl->npj); cl->o_y = take(cl->npj);
     // 512-wide layers: a layer's outputs reach the next one through memory (dudf_sweep_bf16.hip, sweep_tile_w) — one layer's
     // worth of the jet columns, reused by every layer
@@ -308,7 +308,7 @@ int dudf_query_curvature(const dudf_net_cfg* cfg, const float* theta, const floa
     CurvLayout cl;
     int rc = make_curv_layout(cfg, n, &cl);
     if (rc) return rc;
-    if (!workspace || workspace_bytes < cl.total_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    if (!workspace || workspace_bytes < cl.total_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255))
         return DUDF_E_WORKSPACE;
     if (n <= 0) return 0;
     Ctx c;
@@ -568,6 +568,18 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
     const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
     if (which < 0 || which > 7) return DUDF_E_BADMODE;
     return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st);
+}
+
+int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, int64_t* out) {
+    DudfLayout lo;
+    int rc = dudf_make_layout(cfg, n, n_hess, &lo);
+    if (rc) return rc;
+    if (!out) return DUDF_E_BADCFG;
+    const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
+    for (int i = 0; i < 8; ++i) out[i] = offs[i] * (int64_t)sizeof(float);
+    out[8] = lo.np * 16;                                  // bytes between two feature-quad rows
+    out[9] = lo.stash_layer * (int64_t)sizeof(float);     // bytes between two layers
+    return 0;
 }
 
 }  // extern "C"

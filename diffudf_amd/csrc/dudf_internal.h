@@ -77,14 +77,19 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ncols = lo->np;
     // np is the STRIDE (in columns) between the feature-quad rows of every per-column array; ncols the columns processed.
     // np * 16 bytes a large power of two would put all rows of a stash array on the same HBM channels (measured: 131 072
-    // columns ran 1.9x slower per point than 98 304): skew the rows by one 256-byte granule
+    // columns ran 1.9x slower per point than 98 304): skew the rows by one 256-byte granule.  (Skewing EVERY size — the row
+    // stride is always a multiple of 2 KiB — was measured in round 3 and changes nothing at 100 000 points.)
     if (lo->np % 2048 == 0) lo->np += 16;
     lo->off_w1 = 0; lo->off_b1 = 3 * (int64_t)H;
     lo->off_hid = 4 * (int64_t)H; lo->hid_stride = (int64_t)H * H + H;
     lo->off_wo = lo->off_hid + (L - 1) * lo->hid_stride; lo->off_bo = lo->off_wo + H;
     lo->n_theta = lo->off_bo + 1;
     int64_t o = 0;
-    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) / 4 * 4; return r; };
+    // every array starts on a 256-byte boundary of the workspace (whose base the caller aligns to 256 B): a lane quarter's
+    // 256-byte segment of a stash row is then exactly two 128-byte lines.  (Round 3 first put two small arrays of 64 + 128 bytes
+    // in front of the stash: every segment straddled three lines, and FETCH_SIZE / WRITE_SIZE of all four sweeps read 9-12 %
+    // above the algorithmic bytes until this was noticed — profiles/r03_a, r03_b against r02_c.)
+    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64; return r; };
     lo->ws_w1b = take(4 * (int64_t)H);
     lo->ws_w1t16 = take(16 * (int64_t)H);
     lo->ws_wt = take((int64_t)(L - 1) * H * H);

@@ -51,19 +51,33 @@ __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2&
 #define DUDF_AT(arr, ub, vo) reinterpret_cast<f32x4*>(reinterpret_cast<char*>((arr) + (ub)) + (vo))
 #define DUDF_CAT(arr, ub, vo) reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>((arr) + (ub)) + (vo))
 // the stash is a stream (written once, read once or twice, 14 GB per step): non-temporal accesses
+#ifndef DUDF_NT_LD
+#define DUDF_NT_LD 1
+#endif
+#ifndef DUDF_NT_ST
+#define DUDF_NT_ST 1
+#endif
 #ifndef DUDF_SWEEP_DBG
 #define DUDF_SWEEP_DBG 0    // timing experiments only (wrong results): 1 no stash stores, 2 no stash loads, 4 no MFMA (bf16 kernel),
 #endif                      // 8 no weight DMA, 16 no k-block barrier, 32 no LDS fragment reads, 64 no sin/cos
 #if DUDF_SWEEP_DBG & 1
 #define DUDF_ST(arr, ub, vo, val) asm volatile("" :: "v"((f32x4)(val)))
 #else
+#if DUDF_NT_ST
 #define DUDF_ST(arr, ub, vo, val) __builtin_nontemporal_store((f32x4)(val), DUDF_AT(arr, ub, vo))
+#else
+#define DUDF_ST(arr, ub, vo, val) (*DUDF_AT(arr, ub, vo) = (f32x4)(val))
+#endif
 #endif
 #if DUDF_SWEEP_DBG & 2
 __device__ __forceinline__ f32x4 dudf_dbg_any() { f32x4 z; asm volatile("" : "=v"(z)); return z; }
 #define DUDF_LD(arr, ub, vo) dudf_dbg_any()
 #else
+#if DUDF_NT_LD
 #define DUDF_LD(arr, ub, vo) __builtin_nontemporal_load(DUDF_CAT(arr, ub, vo))
+#else
+#define DUDF_LD(arr, ub, vo) (*DUDF_CAT(arr, ub, vo))
+#endif
 #endif
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------

@@ -403,11 +403,15 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
 //   stage instead of in front of them: the two waves of a SIMD then leave the post-barrier lockstep (both splitting,
 //   matrix core idle) after the first slice — one wave's slice runs beside the other's MFMAs.
 #ifndef DUDF_WG_NT
-// Cache policy of the staging loads.  A lane's four loads sit 64 bytes apart, so every 128-byte line is touched by two
-// different instructions; with the non-temporal hint (round 1-2) the second one missed L2 again: PMC FETCH_SIZE 4.17 GB per
-// launch against 2.87 GB of operands, 3.04 GB without the hint, and 0.65-0.68 ms instead of 0.76-0.80 (round 3,
-// tools/pmc_fetch.sh; profiles/r03_wgrad_nt.txt).  A/B: -DDUDF_WG_NT='" nt"'.
+// Cache policy of the staging loads: no non-temporal hint.  A lane's four loads sit 64 bytes apart, so every 128-byte line is
+// touched by two different instructions.  While round 3's workspace layout had the stash 64 bytes off the line grid (fixed:
+// dudf_make_layout), the hinted loads fetched 4.17 GB per launch against 2.87 GB of operands and 3.04 GB without the hint
+// (profiles/r03_wgrad_nt.txt); on the aligned layout both forms fetch 2.87 GB and take the same time.  A/B: -DDUDF_WG_NT_ON=1.
+#if DUDF_WG_NT_ON
+#define DUDF_WG_NT " nt"
+#else
 #define DUDF_WG_NT ""
+#endif
 #endif
 #ifndef DUDF_WG_HREL
 #define DUDF_WG_HREL 2             // flag-synchronised variant: hand the matrix pipe over this many MFMA groups before the end of a stage

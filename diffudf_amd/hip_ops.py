@@ -101,7 +101,7 @@ class Workspace:
         if self.nbytes == 0:
             _lib.check(-1, "dudf_workspace_bytes")
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
-        assert self.buf.data_ptr() % 16 == 0
+        assert self.buf.data_ptr() % 256 == 0
 
 
 class QueryWorkspace(Workspace):

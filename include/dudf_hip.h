@@ -8,7 +8,7 @@
  *   - every pointer is a DEVICE pointer into caller-owned memory unless it says "host";
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
  *   - no allocation inside: the caller passes a workspace of dudf_workspace_bytes() bytes,
- *     16-byte aligned, and must leave it untouched between a *_forward and its *_backward;
+ *     256-byte aligned (so that stash rows start on cache-line boundaries), and must leave it untouched between a *_forward and its *_backward;
  *   - return value: 0 = ok, >0 = hipError_t of a failed launch, <0 = DUDF_E_* below;
  *   - theta = flat fp32 parameters in the reference's state_dict order
  *     (net.0.0.weight (H,3) row-major, net.0.0.bias (H), net.1.0.weight (H,H), ...,
@@ -209,6 +209,12 @@ int dudf_adam_step(float* theta, const float* dtheta, float* exp_avg, float* exp
  * layer: 0-based hidden layer; channel: 0 value, 1..3 tangent (Hessian-path points only). */
 int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int channel, int64_t n, int64_t n_hess,
                           float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host-only diagnostic (no GPU work): where the per-column arrays of a training workspace sit.  out (host, 10 values):
+ * byte offsets of S, C, Q, E, A, Z, R, ZS in the workspace (order of `which` above), then the byte stride between two
+ * feature-quad rows and between two layers.  Every offset and both strides are multiples of 256: a lane quarter's 256-byte
+ * segment is exactly two cache lines (tests/test_cabi_symbols.py holds the layout to that). */
+int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, int64_t* out);
 
 /* One training batch on the GPU — replaces `sampleTrainingData` (reference src/dataset.py:14-70, open3d on the CPU)
  * for a triangle soup tri (n_tri,9) and its precomputed surface cloud pc_pos/pc_nrm (n_pc,3) (reference

@@ -44,3 +44,20 @@ def test_host_only_calls():
     bad = _lib.NetCfg(3, 8, 100, 30.0)
     assert lib.dudf_theta_count(ctypes.byref(bad)) == -1
     assert lib.dudf_workspace_bytes(ctypes.byref(bad), 10) == 0
+
+
+def test_stash_arrays_sit_on_the_cache_line_grid():
+    """Every per-column array starts on a 256-byte boundary of the workspace and its row / layer strides are multiples of
+    256 bytes: a lane quarter's 256-byte segment of a stash row is then exactly two 128-byte lines.  (A 64-byte offset cost
+    9-12 % of HBM traffic in all four sweeps before it was noticed: DESIGN.md §5c, round 3.)"""
+    lib = _lib.load()
+    out = (ctypes.c_int64 * 10)()
+    for hidden, layers in ((256, 8), (512, 8), (128, 3), (64, 2), (32, 1)):
+        cfg = _lib.NetCfg(3, layers, hidden, 30.0)
+        for n, nh in ((100000, 0), (29970, 9990), (125000, 0), (98304, 0), (131072, 0), (1, 0), (17, 17), (1000003, 333)):
+            assert lib.dudf_debug_stash_layout(ctypes.byref(cfg), n, nh, out) == 0
+            vals = list(out)
+            assert all(v % 256 == 0 for v in vals), (hidden, layers, n, nh, vals)
+            assert vals[8] >= 16 * n and vals[9] == vals[8] * hidden // 4
+            assert vals[8] % (1 << 15) != 0, "row stride a large power of two: rows share HBM channels"
+    assert lib.dudf_debug_stash_layout(ctypes.byref(_lib.NetCfg(3, 8, 100, 30.0)), 10, 0, out) != 0
