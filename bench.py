@@ -182,10 +182,13 @@ class Runner:
             eng.profile = False
             buf = ctypes.create_string_buffer(4096)
             self.lib.dudf_profile_dump(buf, len(buf))
-            raw, launches = {}, 0
+            raw, per_step, launches = {}, {}, 0
             for line in buf.value.decode().splitlines():
                 name, cnt, tot = line.split()
-                raw[name] = float(tot) / int(cnt)
+                # ms per STEP of every launch under this name (with Hessian-path points a sweep is two launches: the quad
+                # columns and the plain columns)
+                raw[name] = float(tot) / profile_steps
+                per_step[name] = int(cnt) / profile_steps
                 launches += int(cnt)
             # what bracketing a launch with two events costs: an empty pair reads `ov`, but the events also serialise the
             # stream — the profiled steps are slower than the timed ones by (profiled - timed) spread over the launches of a
@@ -194,7 +197,7 @@ class Runner:
             prof_step = sorted(pm[i].elapsed_time(pm[i + 1]) for i in range(profile_steps))[profile_steps // 2]
             per_launch = max(ov, (prof_step - med) / max(launches / profile_steps, 1.0)) if self.world == 1 else ov
             for name, v in raw.items():
-                info["kern"][name] = max(v - per_launch, 0.0)
+                info["kern"][name] = max(v - per_launch * per_step[name], 0.0)
             info["event_cost_per_launch_ms"] = per_launch
             self.lib.dudf_profile_clocks(buf, len(buf))
             for line in buf.value.decode().splitlines():

@@ -97,6 +97,14 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
 // one sweep over both column ranges: Hessian quads first, then the plain columns
 int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
     int rc = 0;
+    if (lo.ncol_h > 0 && lo.ncol_n > 0 && use_bf16_sweeps()) {     // a training batch with Hessian-path points: one grid for both
+        SweepArgs aq = a, ap = a;
+        aq.tile0 = 0; aq.ntiles = (int)(lo.ncol_h / DUDF_TILE_PTS); aq.hess = 1;
+        ap.tile0 = aq.ntiles; ap.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); ap.hess = 0;
+        rc = dudf_launch_sweep_pair(base, lo.H, aq, ap, st);
+        if (rc != DUDF_E_UNSUPPORTED) return rc;
+        rc = 0;
+    }
     if (lo.ncol_h > 0) {
         a.tile0 = 0; a.ntiles = (int)(lo.ncol_h / DUDF_TILE_PTS); a.hess = 1;
         if (use_bf16_sweeps() && dudf_sweep_bf16_supported(base + 4, lo.H, lo.L)) {

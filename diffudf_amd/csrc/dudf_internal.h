@@ -158,6 +158,7 @@ int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st);
 bool dudf_sweep_bf16_supported(int which, int H, int L);
 bool dudf_sweep_bf16_handles(int which, int H, int L, const SweepArgs& a);
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a, hipStream_t st);
+int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq, const SweepArgs& ap, hipStream_t st);   // quads + plain columns in one grid
 int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);
 
 int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStream_t st);

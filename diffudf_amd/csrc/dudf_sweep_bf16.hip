@@ -43,6 +43,9 @@
 #ifndef DUDF_HI_DMA
 #define DUDF_HI_DMA 0                        // partial passes: the idle half issues the DMA pieces (measured: no gain)
 #endif
+#ifndef DUDF_FWD_F16_KERNEL
+#define DUDF_FWD_F16_KERNEL sweep_f16_np_kernel   // A/B: sweep_f16_kernel = the build WITH packed fp32 instructions
+#endif
 #ifndef DUDF_OCT
 #define DUDF_OCT 1                           // a pass with a single 16-column group is shared by all eight waves (sweep_tile_oct)
 #endif
@@ -899,11 +902,13 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
     }
 }
 
+// (bid, nblk): this workgroup's index among the `nblk` that share the columns of `a` — the whole grid, or one of the two
+// parts of a pair launch (sweep_pair_kernel)
 template <int H, int SW, int FL, int SP = 0>
-__device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
+__device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
-    const bool clk_on = a.clk != nullptr && blockIdx.x == 0;   // profiling: the clock this kernel runs at
+    const bool clk_on = a.clk != nullptr && bid == 0;   // profiling: the clock this kernel runs at
     const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     constexpr int kRow = amax_row<SW, FL>();
     unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
@@ -923,7 +928,7 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
     // balanced shares of 16-column groups; a share is walked in passes of 8 groups, the last one possibly partial —
     // a pass with one wave per SIMD (or a single wave) costs about half a full one, a whole extra round would cost all of it
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
-    const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
+    const int g0 = (int)((int64_t)bid * ng / nblk), g1 = (int)((int64_t)(bid + 1) * ng / nblk);
     constexpr bool kOct = DUDF_OCT && SP != 0 && H == 256 && SW <= SWEEP_ADJ_REV;
     for (int g = g0; g < g1; g += NWB) {
         if constexpr (kOct) {
@@ -933,7 +938,7 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
                 continue;
             }
         }
-        sweep_tile_b<H, SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && blockIdx.x == 100 && g == g0);
+        sweep_tile_b<H, SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && bid == 100 && g == g0);
     }
     if constexpr (kRow >= 0) {
         __syncthreads();
@@ -955,14 +960,25 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a) {
 // (the Hessian-quad and jet variants too: +3 % / +5 % on the Hessian-frame and curvature queries)
 template <int SW> constexpr bool sweep_no_pk() { return SW == SWEEP_FWD || SW >= SWEEP_FWD_H; }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
+__global__ __launch_bounds__(64 * NWB) void sweep_bf16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_bf16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a); }
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_bf16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL>(a, blockIdx.x, gridDim.x); }
 // the fp16x3 builds (own names: tests/isa_contract.py tells the two families apart by them)
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a); }
+__global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a); }
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
+// Pair launch (a batch with Hessian-path points: `loss_s1` with its eigenvector term, the reference's shipped recipe).  A sweep
+// then has two column ranges — the quads (bf16x6, variant SWQ) and the plain columns (fp16x3, variant SWP) — which used to be
+// two launches of <= 256 persistent workgroups each: at the reference's batch (29 970 points = 312 + 156 tiles of 128 columns)
+// that is 1.2 rounds + 0.6 rounds, each rounded up by the tail of its own launch.  Here ONE grid carries both: the first
+// `nbq` workgroups walk the quads, the rest the plain columns, and the host splits the 256 workgroups so that both parts
+// finish together (launch_pair).  The two bodies are the ones above, unchanged.
+template <int H, int SWQ, int FLQ, int SWP, int FLP>
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_pair_kernel(SweepArgs aq, SweepArgs ap, int nbq) {
+    if ((int)blockIdx.x < nbq) sweep_body_b<H, SWQ, FLQ, 0>(aq, blockIdx.x, nbq);
+    else sweep_body_b<H, SWP, FLP, 1>(ap, (int)blockIdx.x - nbq, (int)gridDim.x - nbq);
+}
 
 // theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L
 template <int H>
@@ -1169,9 +1185,9 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         constexpr size_t smem_o = w3 + kMaxAmaxLayers * sizeof(unsigned) + oct;   // + the per-layer running maxima
         bool done = true;
         if (which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {
-            if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3, sweep_f16_np_kernel, smem_fmax, smem_f);
-            else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2, sweep_f16_np_kernel, smem_fmax, smem_f);
-            else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0, sweep_f16_np_kernel, smem_fmax, smem_f);
+            if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
+            else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
+            else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
             else return DUDF_E_BADMODE;
         } else if (which == SWEEP_REV) {
             if (a.train) DUDF_GO_H(SWEEP_REV, 1, sweep_f16_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_REV, 0, sweep_f16_kernel, smem_o, smem_o);
@@ -1621,6 +1637,74 @@ bool dudf_sweep_bf16_handles(int which, int H, int L, const SweepArgs& a) {
 
 bool dudf_sweep_bf16_supported(int which, int H, int L) {
     return (H == 512 || H == 256 || H == 128) && L >= 2 && which >= SWEEP_FWD && which <= SWEEP_FWD_J;
+}
+
+namespace {
+// Estimated duration of one part of a pair launch, in full plain-column passes: every workgroup walks ceil(ng / nb) groups of 16
+// columns in passes of 8 (one per wave); a partial pass with up to one wave per SIMD costs about half a full one (measured: a
+// lone wave 0.68, the passes are bound by latency, not by issue), more waves in proportion.  `c` = a pass of this variant
+// against a pass of the plain fp16x3 sweep (quads on bf16x6: 1.3-1.65 measured at 29 970 points; 1.5 here).
+double pair_est(int ng, int nb, double c) {
+    const int m = (ng + nb - 1) / nb, full = m / NWB, rem = m % NWB;
+    const double part = rem == 0 ? 0.0 : (rem <= NWB / 2 ? 0.55 : 0.55 + 0.45 * (rem - NWB / 2) / (NWB / 2));
+    return c * (full + part);
+}
+constexpr size_t kPairSmemQ = 3 * GeoB<256, 0>::CHUNKB + kMaxAmaxLayers * sizeof(unsigned);                    // the quad body's LDS
+constexpr size_t kPairSmemP = 3 * GeoB<256, 1>::CHUNKB + kMaxLdsBiasLayers * 256 * sizeof(float) + kOctBytes;     // the plain body's, at most
+constexpr size_t kPairSmemMax = kPairSmemQ > kPairSmemP ? kPairSmemQ : kPairSmemP;
+static_assert(kPairSmemMax <= 160 * 1024, "LDS of a CU");
+template <int SWQ, int FLQ, int SWP, int FLP>
+int launch_pair_t(const SweepArgs& aq, const SweepArgs& ap, size_t smem, int nbq, int nbp, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kPairSmemMax);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP>), dim3(nbq + nbp), dim3(GeoB<256>::NTHR), smem, st, aq, ap, nbq);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+// One launch for the quad columns (variant base + 4, bf16x6) AND the plain columns (variant base, fp16x3) of a training sweep
+// at H = 256; DUDF_E_UNSUPPORTED when the combination has no pair kernel (the caller then launches them one after the other).
+// DUDF_PAIR=0 switches it off (A/B).
+int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq0, const SweepArgs& ap0, hipStream_t st) {
+    static const bool off = [] { const char* e = getenv("DUDF_PAIR"); return e && e[0] == '0'; }();
+    if (off || H != 256 || base < SWEEP_FWD || base > SWEEP_ADJ_REV || aq0.ntiles <= 0 || ap0.ntiles <= 0) return DUDF_E_UNSUPPORTED;
+    if (!((ap0.split >> base) & 1) || ap0.L < 2 || ap0.L > kMaxLdsBiasLayers) return DUDF_E_UNSUPPORTED;
+    // the training variants only (a query has no plain columns beside its quads)
+    if (base == SWEEP_FWD && !(aq0.store_s && ap0.store_s && ap0.store_c)) return DUDF_E_UNSUPPORTED;
+    if (base == SWEEP_REV && !(aq0.train && ap0.train)) return DUDF_E_UNSUPPORTED;
+    if (base == SWEEP_ADJ_REV && !(ap0.have_e && ap0.ebound && ((ap0.split >> SWEEP_ADJ_FWD) & 1))) return DUDF_E_UNSUPPORTED;
+    const int ngq = aq0.ntiles * (TILE / 16), ngp = ap0.ntiles * (TILE / 16);
+    const int tq = (ngq + NWB - 1) / NWB, tp = (ngp + NWB - 1) / NWB;          // passes of 8 groups
+    int nbq, nbp;
+    if (tq + tp <= 256) { nbq = tq; nbp = tp; }
+    else {
+        double best = 1e30; nbq = 128;
+        for (int q = 1; q < 256; ++q) {
+            const double eq = pair_est(ngq, q, 1.5), ep = pair_est(ngp, 256 - q, 1.0);
+            const double t = (eq > ep ? eq : ep) + 1e-3 * (eq > ep ? eq - ep : ep - eq);
+            if (t < best) { best = t; nbq = q; }
+        }
+        nbp = 256 - nbq;
+    }
+    DudfProfScope prof(PROF_SWEEP_FWD + base, st);
+    SweepArgs aq = aq0, ap = ap0;
+    aq.clk = nullptr;
+    ap.clk = dudf_prof_clk(PROF_SWEEP_FWD + base);
+    constexpr size_t w3 = 3 * GeoB<256, 1>::CHUNKB;
+    const size_t sp = w3 + (base == SWEEP_FWD ? (size_t)ap.L * 256 * sizeof(float) : kMaxAmaxLayers * sizeof(unsigned)) + kOctBytes;
+    const size_t smem = kPairSmemQ > sp ? kPairSmemQ : sp;
+    switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1>(aq, ap, smem, nbq, nbp, st);
+    }
 }
 
 int dudf_launch_sweep_bf16(int which, int H, const SweepArgs& a0, hipStream_t st) {
