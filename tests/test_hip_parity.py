@@ -410,3 +410,53 @@ def test_weight_gradient_by_layer_ranges(hip, mode, w):
     assert rel(got.cpu().numpy(), ref.cpu().numpy()) < 2e-6
     sl = hip.layer_slices(cfg)
     assert sl[0] == (0, 4 * 256) and sl[L][1] == ref.numel() and all(sl[i][1] == sl[i + 1][0] for i in range(L))
+
+
+def test_pair_launch_agrees_with_separate_launches():
+    """A training batch with Hessian-path points runs every sweep as ONE grid for its quad columns (bf16x6) and its plain
+    columns (fp16x3) (csrc/dudf_sweep_bf16.hip: sweep_pair_kernel; the host splits the 256 workgroups between the two);
+    DUDF_PAIR=0 launches them one after the other.  Same numbers either way — at a size where both parts take several
+    passes per workgroup and the split is uneven (40 000 points, 13 333 on the Hessian path) and at one where the pair has
+    fewer tiles than CUs — and both meet the oracle on a subset of the points."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from diffudf_amd import hip_ops as hip, synth
+hid = [256] * 4
+th = torch.from_numpy(synth.flatten_params(synth.siren_params(hid, seed=31))).cuda()
+out = {}
+for n in (40000, 900):
+    nh = n // 3                                  # the leading on-surface third (synth.training_batch)
+    x, nrm, sdf = [torch.from_numpy(a).cuda() for a in synth.training_batch(n, seed=6, step=0)]
+    cfg = hip.make_cfg(hid)
+    ws = hip.workspace_for(cfg, n, th.device, nh)
+    w = [1e4, 1e4, 1e4, 1e3]
+    terms = hip.loss_forward(cfg, 0, th, x, nrm, sdf.reshape(-1), n, w, 100.0, ws, n_hess=nh)
+    g = hip.loss_backward(cfg, 0, th, x, nrm, sdf.reshape(-1), n, w, 100.0, torch.ones(4, device="cuda"), None, ws, n_hess=nh)
+    out["t%%d" %% n] = terms.cpu().numpy(); out["g%%d" %% n] = g.cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("pair", {}), ("separate", {"DUDF_PAIR": "0"})):
+            path = os.path.join(td, tag + ".npz")
+            e = dict(os.environ); e.update(env)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=600)
+            outs[tag] = dict(np.load(path))
+    for n in (40000, 900):
+        assert rel(outs["pair"]["t%d" % n], outs["separate"]["t%d" % n]) < 2e-6, n
+        # float atomics reorder the sums of d(theta); the Hessian term's own fp32 noise is 6e-5 (the reference's too)
+        assert rel(outs["pair"]["g%d" % n], outs["separate"]["g%d" % n]) < 2e-5, n
+    # the small case against the oracle (the large one costs minutes on the CPU)
+    n = 900
+    P = synth.siren_params([256] * 4, seed=31, dtype=np.float64)
+    x, nrm, sdf = synth.training_batch(n, seed=6, step=0)
+    terms, grads, _ = O.loss_and_grad("s1", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64),
+                                      [1e4, 1e4, 1e4, 1e3], 100.0)
+    gref = np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
+    for tag in ("pair", "separate"):
+        assert rel(outs[tag]["t900"], np.array(list(terms.values()))) < 1e-5, tag
+        assert rel(outs[tag]["g900"], gref) < 5e-4, tag
