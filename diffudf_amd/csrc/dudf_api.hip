@@ -79,6 +79,8 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.wsc = ws + lo.ws_wsc;
     a.amax = reinterpret_cast<unsigned*>(ws + lo.ws_amax);
     a.ebound = (lo.ws_ebound != lo.ws_amax) ? ws + lo.ws_ebound : nullptr;
+    a.zbound = (lo.ws_zbound != lo.ws_amax) ? ws + lo.ws_zbound : nullptr;
+    a.nch = lo.ncol_h;
     a.split = dudf_split_mask();
     a.clk = nullptr;
     a.x4 = ws + lo.ws_x4; a.y = ws + lo.ws_y; a.g = ws + lo.ws_g; a.ybar = ws + lo.ws_ybar; a.gbar = ws + lo.ws_gbar;

@@ -56,7 +56,7 @@ struct DudfLayout {
     // theta
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
-    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_ebound, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
+    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_ebound, ws_zbound, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
     int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array
     size_t total_bytes;
@@ -98,6 +98,9 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_wsc = take(2 * (int64_t)(L > 1 ? L - 1 : 1));
     lo->ws_amax = take(4 * (int64_t)L);
     lo->ws_ebound = query_only ? lo->ws_amax : take((int64_t)L * lo->np);   // [L][np]: max_f |e_l[f][column]| (fp16x3 adjoint reverse sweep)
+    // [L][np]: max_f |zdot_l[f][column]| of the tangent columns of the Hessian quads (left by the fp16x3 forward sweep of the
+    // quads for the column scales of the three sweeps behind it); only a training batch with Hessian-path points has it
+    lo->ws_zbound = (query_only || n_h == 0) ? lo->ws_amax : take((int64_t)L * lo->ncol_h);
     lo->ws_x4 = take(4 * lo->np);
     lo->ws_y = take(lo->np); lo->ws_g = take(4 * lo->np);
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
@@ -133,6 +136,8 @@ struct SweepArgs {
     const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l
     unsigned* amax;           // [4][L]: running maxima of |q_l|, |A_l|, |zbar_l|, |h_l| of the quads (bit patterns), or nullptr
     float* ebound;            // [L][np]: per layer and column, max over features of |e_l| (written by SWEEP_ADJ_FWD), or nullptr
+    float* zbound;            // [L][ncol_h]: per layer and quad column, max over features of |zdot_l| (written by SWEEP_FWD_H, fp16x3), or nullptr
+    int64_t nch;              // ncol_h: row stride of zbound
     unsigned long long* clk;  // profiling: [2] shader-clock / 100 MHz reference-clock ticks of workgroup 0's lifetime, or nullptr
     int split;                // bit s: sweep s (SWEEP_FWD .. SWEEP_ADJ_REV) of the plain columns runs the fp16x3 kernel (DUDF_SPLIT)
     const float* x4;          // [np][4]: layer-1 B operand per column

@@ -222,6 +222,13 @@ extern "C" int dudf_dbg_stamps(unsigned long long* out) {
 #endif
 struct TailOps { f32x4 o1a, o2a, o3a, o1b, o2b, o3b, ba, bb; };   // operands of one pair of tiles (+ bias, forward sweeps)
 
+// LDS offset of the per-layer running maxima: behind the three weight buffers — and behind the biases where the fp16x3 forward
+// sweeps keep them (the quads' forward sweep has both)
+template <int H, int SW, int SP>
+__device__ __forceinline__ unsigned amax_lds_off(const SweepArgs& a) {
+    return 3u * GeoB<H, SP>::CHUNKB + ((SP != 0 && base_of(SW) == SWEEP_FWD) ? (unsigned)(a.L * H * sizeof(float)) : 0u);
+}
+
 // One pass: the workgroup's waves 0..nact-1 take the 16-column groups g_first.. through a whole sweep.  Waves beyond
 // nact (the last, partial pass of a workgroup's share) only keep the weight stream and the barriers going.
 template <int H, int SW, int FL, int SP = 0>
@@ -229,7 +236,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                                              const bool stamp_on = false) {
     using G = GeoB<H, SP>;
     constexpr int NPC = G::NPC;
-    static_assert(SP == 0 || SW <= SWEEP_ADJ_REV, "fp16x3: plain columns");
+    static_assert(SP == 0 || !is_jet(SW), "fp16x3: plain columns and Hessian quads");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -258,7 +265,10 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // column stays below 2^15; a bound that is loose by 2^m costs m of the 16 bits by which fp16's subnormal floor sits
     // below fp32's half ulp of the column maximum.  `unscale` (per lane = per column) turns the accumulators of the matrix
     // that consumed the scaled operand back into true values: 2^-k_j / sb.
-    constexpr bool kColScale = SP != 0 && BS != SWEEP_FWD;
+    // Hessian quads: the forward sweep's tangent channels hdot^k = w0 c zdot^k are not bounded by 1 either, and the other
+    // sweeps' tails couple the four channels of a quad — their bounds (set_scale) take two more per-column maxima: max_f
+    // |zdot_l| of the tangent columns, left per layer by the quads' forward sweep (SweepArgs::zbound), and max_f |e_l|.
+    constexpr bool kColScale = SP != 0 && (BS != SWEEP_FWD || HS);
     constexpr bool kTrackE = SP != 0 && BS == SWEEP_ADJ_FWD;   // (the fp16x3 adjoint reverse sweep therefore needs the fp16x3 adjoint forward one)
     float sb = 1.f, inv_sb = 1.f;                       // scale of the B operand being built (tails of `prev`) and its inverse
     auto colmax = [&](const f32x4 (&t)[G::NT]) -> float {      // max |.| over the 16 tiles' registers and the 4 lane quarters: per column
@@ -274,23 +284,45 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         m = fmaxf(m, __shfl_xor(m, 16));
         return fmaxf(m, __shfl_xor(m, 32));
     };
-    auto set_scale = [&](float amax_true, float extra) {       // extra: the bound of what the tail adds (adjoint reverse: e_l)
-        const float bound = a.w0 * amax_true + extra;
+    // amax_true: max_f |accumulator| of this column (true values); extra: the bound of what the tail adds (adjoint reverse:
+    // e_l); zb: max_f |zdot_l| of this column (quads, tangent channels).  Quads (tails in dudf_sweep_common.h::epilogue):
+    //   forward          value: |sin| <= 1                  tangent k: w0 |zdot^k|
+    //   reverse          value: w0 |a|                       tangent k: w0 (|adot^k| + w0 |zdot^k| |a|)           (a of the value channel)
+    //   adjoint forward  value: w0 (|Q| + w0 sum_k |zdot^k| |Qdot^k|)                tangent k: w0 |Qdot^k|
+    //   adjoint reverse  value: |E| + w0 |hbar| + w0^2 sum_k |zdot^k| |hdotbar^k|   tangent k: |E| + w0 |hdotbar^k|
+    auto set_scale = [&](float amax_true, float extra, float zb) {
+        float bound;
+        if constexpr (!HS) { (void)zb; bound = a.w0 * amax_true + extra; }
+        else if constexpr (BS == SWEEP_FWD) bound = isv ? 1.f : a.w0 * amax_true;
+        else if constexpr (BS == SWEEP_REV) {
+            const float av = quad_bcast0(amax_true);
+            bound = a.w0 * (amax_true + (isv ? 0.f : a.w0 * zb * av));
+        } else {
+            const float sk = quad_sum(isv ? 0.f : zb * amax_true);
+            bound = extra + a.w0 * (amax_true + (isv ? a.w0 * sk : 0.f));
+        }
         unsigned E = (__float_as_uint(bound) >> 23) & 255u;    // bound < 2^(E - 126)
         E = E < 27u ? 27u : (E > 250u ? 250u : E);             // all-zero (padding) columns, infinities: any finite scale will do
         sb = __uint_as_float((268u - E) << 23);                // 2^(15 - (E - 126))
         inv_sb = __uint_as_float((E - 14u) << 23);
     };
     auto ebound_of = [&](int layer) -> float {                 // adjoint reverse sweep with df/dx terms: max_f |e_layer| of this column
-        if constexpr (kColScale && BS == SWEEP_ADJ_REV && (FL & 1) != 0) return a.ebound[(int64_t)layer * a.np + p];
+        if constexpr (kColScale && BS == SWEEP_ADJ_REV && (HS || (FL & 1) != 0)) return a.ebound[(int64_t)layer * a.np + p];
         return 0.f;
     };
-    float eb_next = 0.f;
+    auto zbound_of = [&](int layer) -> float {                 // quads behind the forward sweep: max_f |zdot_layer| of this column
+        if constexpr (kColScale && HS && BS != SWEEP_FWD) return a.zbound[(int64_t)layer * a.nch + p];
+        return 0.f;
+    };
+    auto store_zbound = [&](int layer, float m) {              // the quads' forward sweep leaves it (0 in the value columns)
+        if constexpr (kColScale && HS && BS == SWEEP_FWD) { if (q == 0) a.zbound[(int64_t)layer * a.nch + p] = isv ? 0.f : m; }
+    };
+    float eb_next = 0.f, zb_next = 0.f;
     // running max |.| of what this sweep's tails store for the weight-gradient GEMM (q_l, A_l or zbar_l), per layer: lanes
     // -> one LDS word per layer (ds_max_u32 on the bit patterns: non-negative floats order like integers) -> HBM at kernel end
     constexpr int kRow = amax_row<SW, FL>();
     TailTrack tmax;
-    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + 3 * G::CHUNKB);
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds + amax_lds_off<H, SW, SP>(a));
     auto publish = [&](int layer) {
 #ifdef DUDF_DBG_NOPUBLISH
         if constexpr (kRow >= 0) { asm volatile("" :: "v"(tmax.t)); tmax.t = 0.f; }
@@ -327,7 +359,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // tail of tiles 2kb, 2kb+1 of `layer`: fp32 results (and the stash stores the sweep owes)
     auto run_tail = [&](int layer, int kb, const f32x4 z0, const f32x4 z1, const TailOps& o, f32x4& e0, f32x4& e1) {
         const f32x4 zero = {0, 0, 0, 0};
-        if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
+        if constexpr (BS == SWEEP_FWD && SP != 0 && HS) {   // quads: the bias only in the value channel; `unscale` is this column's
+            const f32x4 us = {unscale, unscale, unscale, unscale};
+            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
+            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+        } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
             e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
             e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
@@ -436,9 +472,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     load_ops(in_layer(0), 0, ops_cur);
     if constexpr (!kOneSet) load_ops(in_layer(0), 1, ops_n1);
     if constexpr (kColScale) {                         // first layer (fp32 MFMA / W_out^T ybar: true values): its column scale
-        const float eb0 = ebound_of(in_layer(0));
-        if (nhid > 0) eb_next = ebound_of(in_layer(1));
-        set_scale(colmax(prev), eb0);
+        const float eb0 = ebound_of(in_layer(0)), zb0 = zbound_of(in_layer(0));
+        if (nhid > 0) { eb_next = ebound_of(in_layer(1)); zb_next = zbound_of(in_layer(1)); }
+        const float cm = colmax(prev);
+        store_zbound(in_layer(0), cm);
+        set_scale(cm, eb0, zb0);
     }
     {
         f32x4 e0, e1;
@@ -621,9 +659,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 if constexpr (kColScale) {
                     // this matrix consumed the operand scaled by sb: its accumulators are 2^k_j sb x the true values
                     unscale = unscale_of(j) * inv_sb;
-                    const float ebl = eb_next;
-                    if (j + 2 <= nhid) eb_next = ebound_of(in_layer(j + 2));   // a layer ahead: its latency hides behind 8 steps
-                    set_scale(colmax(acc) * unscale, ebl);              // ... and the scale of the operand its tails are about to build
+                    const float ebl = eb_next, zbl = zb_next;
+                    if (j + 2 <= nhid) { eb_next = ebound_of(in_layer(j + 2)); zb_next = zbound_of(in_layer(j + 2)); }   // a layer ahead: its latency hides behind 8 steps
+                    const float cm = colmax(acc) * unscale;
+                    store_zbound(lnx, cm);
+                    set_scale(cm, ebl, zbl);                            // ... and the scale of the operand its tails are about to build
                 } else if constexpr (SP) unscale = unscale_of(j);
                 publish(lin);                                           // every tail of layer `lin` has run
                 store_ebound(lin);
@@ -911,7 +951,7 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, 
     const bool clk_on = a.clk != nullptr && bid == 0;   // profiling: the clock this kernel runs at
     const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     constexpr int kRow = amax_row<SW, FL>();
-    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
+    unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_b + amax_lds_off<H, SW, SP>(a));
     if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }   // (sweep_tile_b starts with a barrier)
     if constexpr (SP != 0 && base_of(SW) == SWEEP_FWD) {     // b_1 .. b_L behind the three weight buffers (read by the tails)
         float* lb = reinterpret_cast<float*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
@@ -969,14 +1009,14 @@ __global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { swee
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
 // Pair launch (a batch with Hessian-path points: `loss_s1` with its eigenvector term, the reference's shipped recipe).  A sweep
-// then has two column ranges — the quads (bf16x6, variant SWQ) and the plain columns (fp16x3, variant SWP) — which used to be
+// then has two column ranges — the quads (variant SWQ; fp16x3 or, SPQ = 0, bf16x6) and the plain columns (fp16x3, variant SWP) — which used to be
 // two launches of <= 256 persistent workgroups each: at the reference's batch (29 970 points = 312 + 156 tiles of 128 columns)
 // that is 1.2 rounds + 0.6 rounds, each rounded up by the tail of its own launch.  Here ONE grid carries both: the first
 // `nbq` workgroups walk the quads, the rest the plain columns, and the host splits the 256 workgroups so that both parts
 // finish together (launch_pair).  The two bodies are the ones above, unchanged.
-template <int H, int SWQ, int FLQ, int SWP, int FLP>
+template <int H, int SWQ, int FLQ, int SWP, int FLP, int SPQ>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_pair_kernel(SweepArgs aq, SweepArgs ap, int nbq) {
-    if ((int)blockIdx.x < nbq) sweep_body_b<H, SWQ, FLQ, 0>(aq, blockIdx.x, nbq);
+    if ((int)blockIdx.x < nbq) sweep_body_b<H, SWQ, FLQ, SPQ>(aq, blockIdx.x, nbq);
     else sweep_body_b<H, SWP, FLP, 1>(ap, (int)blockIdx.x - nbq, (int)gridDim.x - nbq);
 }
 
@@ -1198,6 +1238,21 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         } else {
             done = false;
         }
+        if (done) return (int)hipGetLastError();
+    }
+    // ... and the Hessian quads' training sweeps (bit 5, DUDF_SPLIT_QUADS; queries and jets stay on bf16x6).  All four or none:
+    // the forward sweep leaves zbound for the other three, the adjoint forward sweep ebound for the adjoint reverse one.
+    if (which >= SWEEP_FWD_H && which <= SWEEP_ADJ_REV_H && (a.split & 32) && a.zbound && a.ebound && a.L <= kMaxLdsBiasLayers) {
+        constexpr size_t w3 = 3 * GeoB<H, 1>::CHUNKB;
+        const size_t smem_q = w3 + kMaxAmaxLayers * sizeof(unsigned);
+        const size_t smem_fq = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
+        constexpr size_t smem_fqmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
+        bool done = true;
+        if (which == SWEEP_FWD_H && a.store_s) DUDF_GO_H(SWEEP_FWD_H, 1, sweep_f16_np_kernel, smem_fqmax, smem_fq);
+        else if (which == SWEEP_REV_H && a.train) DUDF_GO_H(SWEEP_REV_H, 1, sweep_f16_np_kernel, smem_q, smem_q);
+        else if (which == SWEEP_ADJ_FWD_H) DUDF_GO_H(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
+        else if (which == SWEEP_ADJ_REV_H) DUDF_GO_H(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
+        else done = false;
         if (done) return (int)hipGetLastError();
     }
 #undef DUDF_GO_H
@@ -1653,17 +1708,17 @@ constexpr size_t kPairSmemQ = 3 * GeoB<256, 0>::CHUNKB + kMaxAmaxLayers * sizeof
 constexpr size_t kPairSmemP = 3 * GeoB<256, 1>::CHUNKB + kMaxLdsBiasLayers * 256 * sizeof(float) + kOctBytes;     // the plain body's, at most
 constexpr size_t kPairSmemMax = kPairSmemQ > kPairSmemP ? kPairSmemQ : kPairSmemP;
 static_assert(kPairSmemMax <= 160 * 1024, "LDS of a CU");
-template <int SWQ, int FLQ, int SWP, int FLP>
+template <int SWQ, int FLQ, int SWP, int FLP, int SPQ>
 int launch_pair_t(const SweepArgs& aq, const SweepArgs& ap, size_t smem, int nbq, int nbp, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP, SPQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kPairSmemMax);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP>), dim3(nbq + nbp), dim3(GeoB<256>::NTHR), smem, st, aq, ap, nbq);
+    hipLaunchKernelGGL((sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP, SPQ>), dim3(nbq + nbp), dim3(GeoB<256>::NTHR), smem, st, aq, ap, nbq);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -1698,12 +1753,20 @@ int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq0, const SweepArg
     ap.clk = dudf_prof_clk(PROF_SWEEP_FWD + base);
     constexpr size_t w3 = 3 * GeoB<256, 1>::CHUNKB;
     const size_t sp = w3 + (base == SWEEP_FWD ? (size_t)ap.L * 256 * sizeof(float) : kMaxAmaxLayers * sizeof(unsigned)) + kOctBytes;
-    const size_t smem = kPairSmemQ > sp ? kPairSmemQ : sp;
+    const bool q16 = (aq.split & 32) && aq.zbound && aq.ebound;       // the quads on fp16x3 as well (their LDS is then the smaller part)
+    const size_t sq = q16 ? w3 + (base == SWEEP_FWD ? (size_t)aq.L * 256 * sizeof(float) : 0) + kMaxAmaxLayers * sizeof(unsigned) : kPairSmemQ;
+    const size_t smem = sq > sp ? sq : sp;
+    if (q16) switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1>(aq, ap, smem, nbq, nbp, st);
+    }
     switch (base) {
-        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0>(aq, ap, smem, nbq, nbp, st);
-        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 0>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 0>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 0>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 0>(aq, ap, smem, nbq, nbp, st);
     }
 }
 

@@ -237,6 +237,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         DUDF_ST(a.A, ub, vo, out);
         DUDF_ST(a.E, ub, vo, e);
+        if constexpr (TE) dudf_track(tk.e, e);
     } else if constexpr (SW == SWEEP_FWD_J) {
         const int lane = threadIdx.x & 63, l0 = lane & 48;
         const unsigned jw = kJetLane[lane & 15];

@@ -319,6 +319,35 @@ def test_fp16x3_range_scaling(hip, scale):
         assert rel(g2.cpu().numpy(), flat(g_ref)) < (1e-4 if k < 1 else 3e-4), k
 
 
+@pytest.mark.parametrize("scale", [1e-10, 1e8])
+def test_fp16x3_range_scaling_hessian_quads(hip, scale):
+    """The same for the Hessian quads (fp16x3 since round 3: csrc/dudf_sweep_bf16.hip, `set_scale`): their tails couple the four
+    channels of a quad, so a column's power of two comes from a bound over its own and its quad's accumulators, max_f |zdot_l|
+    (left by the quads' forward sweep) and max_f |e_l|.  Linear in the upstream cotangent over 18 decades; a network with 4x
+    larger hidden weights (tangent channels ~4^L larger) against the oracle."""
+    hidden, n = [256] * 4, 600
+    P, theta, x, nrm, sdf = setup(hidden, n, 23)
+    n_on = n // 3
+    cfg = hip.make_cfg(hidden)
+    ws = hip.workspace_for(cfg, n, "cuda", n_hess=n_on)
+    th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf.reshape(-1))
+    hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, ws, n_hess=n_on)
+    g1 = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, torch.ones(4, device="cuda"), None, ws, n_hess=n_on).clone()
+    gs = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, torch.full((4,), scale, device="cuda"), None, ws, n_hess=n_on)
+    assert torch.isfinite(gs).all()
+    assert rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy()) < 5e-6, scale
+    if scale > 1:
+        k = 4.0
+        P2 = [(w * (k if 0 < i < len(P) - 1 else 1.0), b) for i, (w, b) in enumerate(P)]
+        th2 = dev(np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in P2]).astype(np.float32))
+        P2 = [(w.astype(np.float32).astype(np.float64), b) for w, b in P2]
+        terms = hip.loss_forward(cfg, hip.LOSS_S1, th2, xd, nd, sd, n, W_S1FULL, 100.0, ws, n_hess=n_on)
+        g2 = hip.loss_backward(cfg, hip.LOSS_S1, th2, xd, nd, sd, n, W_S1FULL, 100.0, torch.ones(4, device="cuda"), None, ws, n_hess=n_on)
+        t_ref, g_ref, _ = O.loss_and_grad("s1", P2, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), W_S1FULL, 100.0)
+        assert rel(terms.cpu().numpy(), np.array([float(v) for v in t_ref.values()])) < 2e-5, k
+        assert rel(g2.cpu().numpy(), flat(g_ref)) < 2e-3, k          # sine arguments of hundreds of radians: fp32's own floor
+
+
 def test_deterministic_mode_is_bit_reproducible():
     """DUDF_DETERMINISTIC=1 (SURVEY.md §5 'race detection' row): every cross-workgroup sum has one owner, so loss terms,
     loss_s2 statistics and d(theta) are BIT-IDENTICAL across launches — for the Eikonal loss, the Hessian loss (quad
@@ -441,12 +470,15 @@ np.savez(sys.argv[1], **out)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, env in (("pair", {}), ("separate", {"DUDF_PAIR": "0"})):
+        for tag, env in (("pair", {}), ("separate", {"DUDF_PAIR": "0"}), ("quads_bf16", {"DUDF_SPLIT_QUADS": "0"})):
             path = os.path.join(td, tag + ".npz")
             e = dict(os.environ); e.update(env)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=600)
             outs[tag] = dict(np.load(path))
     for n in (40000, 900):
+        # the quads on bf16x6 (six products) instead of fp16x3: same tolerances, agreement far inside the Hessian term's noise
+        assert rel(outs["pair"]["t%d" % n], outs["quads_bf16"]["t%d" % n]) < 5e-6, n
+        assert rel(outs["pair"]["g%d" % n], outs["quads_bf16"]["g%d" % n]) < 2e-4, n
         assert rel(outs["pair"]["t%d" % n], outs["separate"]["t%d" % n]) < 2e-6, n
         # float atomics reorder the sums of d(theta); the Hessian term's own fp32 noise is 6e-5 (the reference's too)
         assert rel(outs["pair"]["g%d" % n], outs["separate"]["g%d" % n]) < 2e-5, n
@@ -457,6 +489,6 @@ np.savez(sys.argv[1], **out)
     terms, grads, _ = O.loss_and_grad("s1", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64),
                                       [1e4, 1e4, 1e4, 1e3], 100.0)
     gref = np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in grads])
-    for tag in ("pair", "separate"):
+    for tag in ("pair", "separate", "quads_bf16"):
         assert rel(outs[tag]["t900"], np.array(list(terms.values()))) < 1e-5, tag
         assert rel(outs[tag]["g900"], gref) < 5e-4, tag
