@@ -97,16 +97,26 @@ __device__ __forceinline__ double tri_dist2(double px, double py, double pz, con
 }
 
 constexpr int TRI_TILE = 256;
+constexpr int QSPLIT = 8;                 // lanes that share one query point (each scans every QSPLIT-th triangle of a tile)
 
+// Brute force over the triangles, organised for the GPU (round 3: this kernel was a third of the beetle recipe's GPU time —
+// one thread per point on 118 workgroups, 78 of which did all the distance work):
+//   * QSPLIT adjacent lanes share a point and scan interleaved triangles; the minimum over lanes is exact, so the result is
+//     bit-identical to the one-thread scan (and to oracle/sampler_oracle.py);
+//   * a triangle whose bounding sphere lies farther than the lane's current best is skipped without the Voronoi-region
+//     arithmetic: |p - c| - r > sqrt(best) in fp64, with r rounded UP — a conservative test, the minimum is unchanged.
 __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
     // no a*b+c -> fma here: the oracle (numpy) rounds the product of normal and offset to fp32 before the add, and HIP's
     // __fmul_rn / __fadd_rn are plain operators that hipcc's default -ffp-contract=fast would fuse (measured: 48 of 999
     // near points off by one ulp)
 #pragma clang fp contract(off)
     __shared__ float tl[TRI_TILE * 9];
+    __shared__ float4 ts[TRI_TILE];                     // bounding sphere of each staged triangle: centre, radius (rounded up)
     const int64_t n_on_l = a.on1 - a.on0, n_far_l = a.far1 - a.far0, n_near_l = a.near1 - a.near0;
     const int64_t n_l = n_on_l + n_far_l + n_near_l;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid / QSPLIT;
+    const int part = (int)(gid % QSPLIT);
     const bool live = i < n_l;
     float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, known = 0.f;
     bool query = false;
@@ -136,14 +146,40 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
             known = fabsf(off);
         }
     }
-    double best = 3.0e38;
+    double best = 3.0e38, sbest = 1.7e19;               // sbest >= sqrt(best), refreshed whenever best improves
+    const double dpx = px, dpy = py, dpz = pz;
     for (int64_t t0 = 0; t0 < a.n_tri; t0 += TRI_TILE) {
         const int cnt = (int)((a.n_tri - t0 < TRI_TILE) ? a.n_tri - t0 : TRI_TILE);
         __syncthreads();
         for (int e = threadIdx.x; e < cnt * 9; e += blockDim.x) tl[e] = a.tri[t0 * 9 + e];
         __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const float* t = tl + threadIdx.x * 9;
+            const float cx = (t[0] + t[3] + t[6]) * (1.f / 3.f), cy = (t[1] + t[4] + t[7]) * (1.f / 3.f), cz = (t[2] + t[5] + t[8]) * (1.f / 3.f);
+            double r2 = 0.0;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double dx = (double)t[3 * v] - cx, dy = (double)t[3 * v + 1] - cy, dz = (double)t[3 * v + 2] - cz;
+                r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+            }
+            ts[threadIdx.x] = make_float4(cx, cy, cz, (float)(sqrt(r2) * 1.000001) + 1e-30f);   // >= the true radius about (cx, cy, cz)
+        }
+        __syncthreads();
         if (query)
-            for (int t = 0; t < cnt; ++t) best = fmin(best, tri_dist2((double)px, (double)py, (double)pz, tl + t * 9));
+            for (int t = part; t < cnt; t += QSPLIT) {
+                const float4 sp = ts[t];
+                const double dx = dpx - sp.x, dy = dpy - sp.y, dz = dpz - sp.z;
+                const double lim = sbest + (double)sp.w;
+                if (dx * dx + dy * dy + dz * dz > lim * lim * 1.0000000001) continue;    // the whole triangle is farther than best
+                const double d2 = tri_dist2(dpx, dpy, dpz, tl + t * 9);
+                if (d2 < best) { best = d2; sbest = sqrt(d2) * 1.0000000001; }
+            }
+        // the lanes of a point pool what they have found (the final answer is their minimum anyway): a tighter bound for
+        // every lane's next tile
+        double pooled = best;
+#pragma unroll
+        for (int m = 1; m < QSPLIT; m <<= 1) pooled = fmin(pooled, __shfl_xor(pooled, m));
+        if (pooled < best) { best = pooled; sbest = sqrt(pooled) * 1.0000000001; }
     }
     if (cloud_only)
         for (int64_t t0 = 0; t0 < a.n_pc; t0 += TRI_TILE * 3) {         // the same LDS tile holds 768 cloud points
@@ -152,12 +188,15 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
             for (int e = threadIdx.x; e < cnt * 3; e += blockDim.x) tl[e] = a.pc_pos[t0 * 3 + e];
             __syncthreads();
             if (query)
-                for (int t = 0; t < cnt; ++t) {
-                    const double dx = (double)px - tl[t * 3], dy = (double)py - tl[t * 3 + 1], dz = (double)pz - tl[t * 3 + 2];
+                for (int t = part; t < cnt; t += QSPLIT) {
+                    const double dx = dpx - tl[t * 3], dy = dpy - tl[t * 3 + 1], dz = dpz - tl[t * 3 + 2];
                     best = fmin(best, dx * dx + dy * dy + dz * dz);
                 }
         }
-    if (live) {
+    // the QSPLIT lanes of a point are adjacent lanes of one wave (256 % QSPLIT == 0, 64 % QSPLIT == 0)
+#pragma unroll
+    for (int m = 1; m < QSPLIT; m <<= 1) best = fmin(best, __shfl_xor(best, m));
+    if (live && part == 0) {
         a.x[i * 3] = px; a.x[i * 3 + 1] = py; a.x[i * 3 + 2] = pz;
         a.normals[i * 3] = nx; a.normals[i * 3 + 1] = ny; a.normals[i * 3 + 2] = nz;
         a.sdf[i] = query ? (float)sqrt(best) : known;
@@ -187,6 +226,6 @@ extern "C" int dudf_sample_batch(const float* tri, int64_t n_tri, const float* p
     if (n_l == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DudfProfScope prof(PROF_OTHER, st);
-    hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((n_l * QSPLIT + 255) / 256)), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }

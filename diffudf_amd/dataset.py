@@ -39,6 +39,11 @@ class SyntheticPointCloud:
     def local_indices(self):
         return synth.stratified_shard(self.n_global, self.rank, self.world)
 
+    @property
+    def n_on_surface(self):
+        """Leading on-surface points of THIS rank's batch ([on | far | near]; train.py passes it to loss_s1 as a hint)."""
+        return int((self.local_indices() < self.n_global // 3).sum())
+
     def __iter__(self):
         for _ in range(self.batchesPerEpoch):
             idx = self.local_indices()
@@ -89,6 +94,11 @@ class PointCloud:
     def n_local(self):
         sl = lambda m: m * (self.rank + 1) // self.world - m * self.rank // self.world   # noqa: E731
         return sl(self.samplesOnSurface), sl(self.n_far), sl(self.n_near)
+
+    @property
+    def n_on_surface(self):
+        """Leading on-surface points of THIS rank's batch ([on | far | near]; train.py passes it to loss_s1 as a hint)."""
+        return self.n_local()[0]
 
     def sample(self, step):
         """(x (n,3), normals (n,3), sdf (n,)) device tensors for global step `step`; n_on leading on-surface points."""

@@ -38,24 +38,34 @@ def _prep(model_input, gt):
     return x, normals, sdf
 
 
-def _on_surface_first(x, normals, sdf):
-    """(x, normals, sdf, n_on) with the sdf == 0 points leading (one device->host sync for the count)."""
+def _on_surface_first(x, normals, sdf, n_on_hint=None):
+    """(x, normals, sdf, n_on, ok) with the sdf == 0 points leading.
+
+    Without a hint the count costs two device->host syncs per call (the launch geometry depends on it).  A batch source that
+    KNOWS its layout — the reference sampler's [on | far | near], `gt['n_on_surface']` — passes the count instead; it is then
+    checked on the device only (`ok`: a 0-dim bool tensor, no sync) and a wrong hint turns every loss term into NaN."""
     on = sdf == 0
+    if n_on_hint is not None:
+        n_on = int(n_on_hint)
+        if not 0 <= n_on <= sdf.shape[0]:
+            raise ValueError("gt['n_on_surface'] outside [0, number of points]")
+        ok = on[:n_on].all() & ~on[n_on:].any()
+        return x, normals, sdf, n_on, ok
     n_on = int(on.sum())
     if n_on == 0 or bool(on[:n_on].all()):
-        return x, normals, sdf, n_on
+        return x, normals, sdf, n_on, None
     perm = torch.argsort((~on).to(torch.int8), stable=True)
-    return x[perm].contiguous(), normals[perm].contiguous(), sdf[perm].contiguous(), n_on
+    return x[perm].contiguous(), normals[perm].contiguous(), sdf[perm].contiguous(), n_on, None
 
 
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, mode, x, normals, sdf, weights, alpha, n_global, *params):
+    def forward(ctx, model, mode, x, normals, sdf, weights, alpha, n_global, n_on_hint, *params):
         cfg = model.hip_cfg
         theta = model.flat_parameters()
-        n_hess = 0
+        n_hess, ok = 0, None
         if mode == hip_ops.LOSS_S1 and weights[2] != 0:
-            x, normals, sdf, n_hess = _on_surface_first(x, normals, sdf)
+            x, normals, sdf, n_hess, ok = _on_surface_first(x, normals, sdf, n_on_hint)
         ws = hip_ops.workspace_for(cfg, x.shape[0], x.device, n_hess=n_hess)
         ws.generation = getattr(ws, "generation", 0) + 1
         stats = None
@@ -67,6 +77,8 @@ class _FusedLoss(torch.autograd.Function):
             terms = hip_ops.s2_terms(stats, weights)
         else:
             terms = hip_ops.loss_forward(cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, ws, n_hess=n_hess)
+            if ok is not None:                         # a wrong layout hint must not train silently
+                terms = torch.where(ok, terms, torch.full_like(terms, float("nan")))
         ctx.model, ctx.mode, ctx.ws, ctx.stats, ctx.n_hess = model, mode, ws, stats, n_hess
         ctx.args = (x, normals, sdf, list(weights), alpha, n_global)
         ctx.stamp = ws.generation
@@ -84,14 +96,14 @@ class _FusedLoss(torch.autograd.Function):
         theta = model.flat_parameters()
         dtheta = hip_ops.loss_backward(model.hip_cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot,
                                        ctx.stats, ws, n_hess=ctx.n_hess)
-        return (None,) * 8 + tuple(model.split_flat(dtheta))
+        return (None,) * 9 + tuple(model.split_flat(dtheta))
 
 
 def _run(model, mode, model_input, gt, loss_weights, alpha, keys):
     x, normals, sdf = _prep(model_input, gt)
     n_global = int(getattr(model, "dudf_n_global", 0) or x.shape[0])
     terms = _FusedLoss.apply(model, mode, x, normals, sdf, tuple(float(w) for w in loss_weights), float(alpha),
-                             n_global, *model.parameters())
+                             n_global, gt.get('n_on_surface'), *model.parameters())
     return {k: terms[i] for i, k in enumerate(keys)}
 
 

@@ -46,6 +46,30 @@ def batch(n, seed, step=0):
 W_S1FULL = [1e4, 1e4, 1e4, 1e3]
 
 
+def test_on_surface_count_hint():
+    """`gt['n_on_surface']` (what train.py passes for the sampler's [on | far | near] batches) spares loss_s1 the two host syncs
+    that counting the sdf == 0 points costs; it is verified on the device: the right count gives the same terms as no hint,
+    a wrong one turns every term into NaN instead of training on a mislabelled batch."""
+    from src.loss_functions import loss_s1
+    model, P = make_model([256] * 4, 5)
+    (x, nrm, sdf), (xd, nd, sd) = batch(600, 17)
+    n_on = int((sdf[:, 0] == 0).sum())
+    ref = loss_s1(model, xd, {"normals": nd, "sdf": sd}, W_S1FULL, 100)
+    ref_vals = [v.item() for v in ref.values()]
+    hinted = loss_s1(model, xd, {"normals": nd, "sdf": sd, "n_on_surface": n_on}, W_S1FULL, 100)
+    assert [v.item() for v in hinted.values()] == ref_vals
+    sum(hinted.values()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    for wrong in (n_on - 1, n_on + 1):
+        bad = loss_s1(model, xd, {"normals": nd, "sdf": sd, "n_on_surface": wrong}, W_S1FULL, 100)
+        assert all(np.isnan(v.item()) for v in bad.values()), wrong
+    with pytest.raises(ValueError):
+        loss_s1(model, xd, {"normals": nd, "sdf": sd, "n_on_surface": 601}, W_S1FULL, 100)
+    # without the Hessian term the hint is not needed and not looked at
+    eik = loss_s1(model, xd, {"normals": nd, "sdf": sd, "n_on_surface": 3}, W_S1EIK, 100)
+    assert all(np.isfinite(v.item()) for v in eik.values())
+
+
 @pytest.mark.parametrize("case", ["s1eik", "s1full", "s1full_shuffled", "s2", "siren"])
 def test_loss_dict_and_param_grads(case):
     from src.loss_functions import loss_s1, loss_s2, loss_siren

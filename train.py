@@ -106,29 +106,29 @@ def _train(dataset, model, device, config, schedule):
     best_loss = np.inf
     best_weights = None
     recon_time = 0
-    start_ttime = time.time()
-    for epoch in range(epochs):
-        loss_fn, loss_weights, current_lr, extra = schedule(epoch)
-        if current_lr is not None:
-            for g in optim.param_groups:
-                g['lr'] = current_lr
+    keys = list(model.state_dict().keys())
+
+    # The reference reads every loss term back right after the step (five .item() syncs, reference train.py:212-224), so
+    # the GPU idles while Python prepares the next step.  Here an epoch's numbers are read back ONE EPOCH LATER: its per-step
+    # terms go to a pinned host buffer behind an event, and the parameters it ended with are kept in one of two device
+    # snapshots (1.8 MB, a device-to-device copy) — so the bookkeeping below (losses.csv, the printed line, best / current /
+    # periodic checkpoints) sees exactly the values and weights of ITS epoch, in the same order, while the next epoch's
+    # kernels are already queued.
+    snaps = [torch.empty_like(model.flat_parameters()) for _ in range(2)]
+
+    def snapshot_state(flat):
+        return {k: v.clone() for k, v in zip(keys, model.split_flat(flat))}
+
+    def finish(rec):
+        """Epoch bookkeeping of reference train.py:226-283 for the epoch recorded in `rec`."""
+        nonlocal best_loss, best_weights, recon_time
+        epoch, names, host, event, snap, lr_now = rec
+        event.synchronize()
         running_loss = dict()
-        for input_data, normals, sdf in iter(dataset):
-            flat_grad = _zero_flat_grad(model)
-            input_data = input_data.to(device); normals = normals.to(device); sdf = sdf.to(device)
-            loss = loss_fn(model, input_data, {'normals': normals, 'sdf': sdf}, loss_weights, *extra)
-            train_loss = torch.zeros((1, 1), device=device)
-            vals = torch.stack([l.reshape(()) for l in loss.values()]).detach()
-            for l in loss.values():
-                train_loss += l
-            train_loss.backward()
-            vals = _allreduce_step(flat_grad, vals, terms_are_global=loss_fn is loss_s2)
-            optim.step()
-            vals = vals.tolist()                       # ONE device->host sync per step (the reference does five)
-            for (it, _), v in zip(loss.items(), vals):
+        for vals in host.tolist():                     # one row per step of the epoch
+            for it, v in zip(names, vals):
                 running_loss[it] = running_loss.get(it, 0.0) + v
             writer.add_scalar("train_loss", sum(vals), epoch)
-
         for it, l in running_loss.items():
             if it not in losses:
                 losses[it] = [0.] * epochs
@@ -136,22 +136,56 @@ def _train(dataset, model, device, config, schedule):
             writer.add_scalar(it, l, epoch)
         epoch_loss = sum(running_loss.values()) / dataset.batchesPerEpoch
         if _is_main():
-            lr_now = optim.param_groups[0]['lr']
             print(f"Epoch: {epoch} - Loss: {epoch_loss} - Learning Rate: {lr_now:.3e}")
-
         start_rtime = time.time()
         if _is_main():
             if epoch_loss < best_loss:
                 best_loss = epoch_loss
-                best_weights = copy.deepcopy(model.state_dict())
+                best_weights = snapshot_state(snap)
                 if config.get("save_every_epoch", True):
                     torch.save(best_weights, osp.join(log_path, "models", "model_best.pth"))
             if epoch and epochs_til_checkpoint and (not epoch % epochs_til_checkpoint):
                 print(f"Saving model for epoch {epoch}")
-                torch.save(model.state_dict(), osp.join(log_path, "models", f"model_{epoch}.pth"))
+                torch.save(snapshot_state(snap), osp.join(log_path, "models", f"model_{epoch}.pth"))
             elif config.get("save_every_epoch", True):
-                torch.save(model.state_dict(), osp.join(log_path, "models", "model_current.pth"))
+                torch.save(snapshot_state(snap), osp.join(log_path, "models", "model_current.pth"))
         recon_time += time.time() - start_rtime
+
+    pending = None
+    start_ttime = time.time()
+    for epoch in range(epochs):
+        loss_fn, loss_weights, current_lr, extra = schedule(epoch)
+        if current_lr is not None:
+            for g in optim.param_groups:
+                g['lr'] = current_lr
+        step_vals, names = [], None
+        for input_data, normals, sdf in iter(dataset):
+            flat_grad = _zero_flat_grad(model)
+            input_data = input_data.to(device); normals = normals.to(device); sdf = sdf.to(device)
+            gt = {'normals': normals, 'sdf': sdf}
+            if getattr(dataset, 'n_on_surface', None) is not None:
+                gt['n_on_surface'] = dataset.n_on_surface      # [on | far | near]: spares loss_s1 its two syncs for the count
+            loss = loss_fn(model, input_data, gt, loss_weights, *extra)
+            train_loss = torch.zeros((1, 1), device=device)
+            vals = torch.stack([l.reshape(()) for l in loss.values()]).detach()
+            for l in loss.values():
+                train_loss += l
+            train_loss.backward()
+            vals = _allreduce_step(flat_grad, vals, terms_are_global=loss_fn is loss_s2)
+            optim.step()
+            step_vals.append(vals)
+            names = list(loss.keys())
+        snap = snaps[epoch & 1]
+        snap.copy_(model.flat_parameters())
+        host = torch.empty((len(step_vals), len(names)), dtype=torch.float32, pin_memory=True)
+        host.copy_(torch.stack(step_vals), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        if pending is not None:
+            finish(pending)                            # the PREVIOUS epoch's numbers: this epoch's kernels are queued behind them
+        pending = (epoch, names, host, event, snap, optim.param_groups[0]['lr'])
+    if pending is not None:
+        finish(pending)
 
     if torch.cuda.is_available():
         torch.cuda.synchronize()
