@@ -58,6 +58,9 @@ def _on_surface_first(x, normals, sdf, n_on_hint=None):
     return x[perm].contiguous(), normals[perm].contiguous(), sdf[perm].contiguous(), n_on, None
 
 
+STATS = {"direct_grad": 0}      # diagnostics: backward() calls that wrote straight into the flat gradient buffer
+
+
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, mode, x, normals, sdf, weights, alpha, n_global, n_on_hint, *params):
@@ -94,6 +97,19 @@ class _FusedLoss(torch.autograd.Function):
         cot = torch.zeros(4, dtype=torch.float32, device=x.device)
         cot[:grad_terms.numel()] = grad_terms.float()
         theta = model.flat_parameters()
+        # A loop that keeps every p.grad as a view of ONE flat buffer (train.py::_zero_flat_grad) gets the gradient written —
+        # accumulated, as autograd would — straight into it: no temporary, none of the 18 per-parameter add kernels of
+        # AccumulateGrad.  Anything else (fresh .grad, foreign tensors): the gradients are returned to autograd as usual.
+        flat = getattr(model, "_dudf_flat_grad", None)
+        sig = getattr(model, "_dudf_flat_grad_sig", None)
+        if flat is not None and sig is not None and flat.device == theta.device and flat.numel() >= theta.numel():
+            params = list(model.parameters())
+            if len(sig) == len(params) and all(p.grad is not None and p.grad.data_ptr() == ptr and p.grad.stride() == stride
+                                                 for p, (ptr, stride) in zip(params, sig)):
+                hip_ops.loss_backward(model.hip_cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot,
+                                      ctx.stats, ws, dtheta=flat[:theta.numel()], accumulate=True, n_hess=ctx.n_hess)
+                STATS["direct_grad"] += 1
+                return (None,) * (9 + len(params))
         dtheta = hip_ops.loss_backward(model.hip_cfg, mode, theta, x, normals, sdf, n_global, weights, alpha, cot,
                                        ctx.stats, ws, n_hess=ctx.n_hess)
         return (None,) * 9 + tuple(model.split_flat(dtheta))

@@ -103,7 +103,13 @@ class SIREN(nn.Module):
         return [blk[0] for blk in self.net]
 
     def _padded_dims(self):
-        """[(rows, cols)] of every layer's weight in the C-ABI layout: SIREN(n_in, n_out, [Hp]*L)."""
+        """[(rows, cols)] of every layer's weight in the C-ABI layout: SIREN(n_in, n_out, [Hp]*L) (fixed at construction)."""
+        dims = self.__dict__.get("_dims_cache")
+        if dims is None:
+            dims = self.__dict__["_dims_cache"] = self._padded_dims_uncached()
+        return dims
+
+    def _padded_dims_uncached(self):
         L = len(self.hidden_layer_config)
         if L == 0:
             return [(self.n_out_features, self.n_in_features)]
@@ -139,18 +145,25 @@ class SIREN(nn.Module):
             ref = lins[0].weight
             flat = torch.zeros(self._flat_numel(), dtype=ref.dtype, device=ref.device)
             params = [p for l in lins for p in (l.weight, l.bias)]
-            for p, v in zip(params, self._views_of(flat)):
+            views = self._views_of(flat)
+            for p, v in zip(params, views):
                 v.copy_(p.detach())
                 p.data = v
         self._flat = flat
+        # what "every parameter still aliases the flat buffer" means, as plain numbers: flat_parameters() runs several times per
+        # training step and must not rebuild 18 views to find out
+        self.__dict__["_flat_sig"] = [(v.data_ptr(), v.stride()) for v in views]
 
     def _is_flat(self):
         if self._flat is None:
             return False
+        sig = self.__dict__.get("_flat_sig")
+        if sig is None:
+            return False
         params = [p for l in self._linears() for p in (l.weight, l.bias)]
-        for p, v in zip(params, self._views_of(self._flat)):
-            if (p.data_ptr() != v.data_ptr() or p.stride() != v.stride() or p.dtype != self._flat.dtype
-                    or p.device != self._flat.device):
+        dt, dev = self._flat.dtype, self._flat.device
+        for p, (ptr, stride) in zip(params, sig):
+            if p.data_ptr() != ptr or p.stride() != stride or p.dtype != dt or p.device != dev:
                 return False
         return True
 

@@ -4,7 +4,7 @@
     bash tools/build_dbg.sh stw sweep_bf16 "-DDUDF_SWEEP_DBG=128"; DUDF_LIB=dbg/libdudf_stw.so python tools/phase_timeline_wide.py
 k-loop / tail burst / drain + barrier, in shader-clock cycles, for waves 0 and 4 of two workgroups (8x512, 125 000 points)."""
 import ctypes, os, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from diffudf_amd import _lib, hip_ops, synth
 from diffudf_amd.engine import TrainEngine

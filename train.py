@@ -60,13 +60,15 @@ def _zero_flat_grad(model):
     per-step torch.cat / copy-back."""
     flat = getattr(model, "_dudf_flat_grad", None)
     theta = model.flat_parameters()
-    if flat is None or flat.device != theta.device or flat.numel() != theta.numel() + 4:
+    views = getattr(model, "_dudf_flat_grad_views", None)
+    if flat is None or views is None or flat.device != theta.device or flat.numel() != theta.numel() + 4:
         flat = model._dudf_flat_grad = torch.zeros(theta.numel() + 4, dtype=torch.float32, device=theta.device)
+        views = model._dudf_flat_grad_views = model.split_flat(flat[:theta.numel()])
+        model._dudf_flat_grad_sig = [(v.data_ptr(), v.stride()) for v in views]
     else:
         flat.zero_()
-    views = model.split_flat(flat[:theta.numel()])
-    for p, v in zip(model.parameters(), views):
-        if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+    for p, v, (ptr, _) in zip(model.parameters(), views, model._dudf_flat_grad_sig):
+        if p.grad is None or p.grad.data_ptr() != ptr:
             p.grad = v
     return flat
 
