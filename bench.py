@@ -245,7 +245,7 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
             continue
         tf = fl * n_cols / (kern[k] * 1e-3) / 1e12
         if k in on16:
-            fp16 = bool((mode >> SPLIT_BIT.get(k, 31)) & 1) and fp16_ok.get(k, False) and n_hess == 0
+            fp16 = bool((mode >> SPLIT_BIT.get(k, 31)) & 1) and fp16_ok.get(k, False) and (n_hess == 0 or bool(mode & 32))   # bit 5: the quads too
             name, mult, peak = ("fp16x3", 3, PEAK_BF16_MFMA_TFLOPS) if fp16 else ("bf16x6", 6, PEAK_BF16_MFMA_TFLOPS)
         else:
             name, mult, peak = "f32", 1, PEAK_F32_MFMA_TFLOPS
