@@ -1,0 +1,65 @@
+# coding: utf-8
+"""`torch.optim.Adam` for a `diffudf_amd.model.SIREN` whose parameters and gradients live in flat buffers.
+
+The reference constructs `torch.optim.Adam(lr=..., params=model.parameters())` (reference train.py:334-337, defaults
+betas (0.9, 0.999), eps 1e-8, no weight decay) and only ever calls `step()` and edits `param_groups[*]['lr']`.  This class
+IS that optimizer — same constructor, same `param_groups`, and `step()` falls back to torch's implementation whenever its
+fast path does not apply — but when every parameter is a view of the model's flat theta and every `.grad` a view of the
+flat gradient buffer (what `train.py::_zero_flat_grad` sets up), one `dudf_adam_step` launch updates everything: the kernel
+replays torch's CUDA Adam operation by operation (csrc/dudf_misc.hip; tests/test_api_gpu.py holds a 10-step trajectory to
+2e-7), instead of torch's six foreach launches over 18 tensors and their host-side bookkeeping (0.3 ms of Python a step,
+which is what the stage-2 epochs of the reference recipe are bound by).  The fast path's moments are flat tensors of its
+own: `state_dict()` then carries no per-parameter state (the reference never saves the optimizer).
+"""
+import torch
+
+from . import hip_ops
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, model=None, **kw):
+        super().__init__(params, lr=lr, **kw)
+        self._model = model
+        self._m = self._v = None
+        self._t = 0
+        self._fell_back = False
+
+    def _flat_views(self):
+        """(theta, dtheta) if the fast path applies right now, else None."""
+        m = self._model
+        if m is None or self._fell_back or len(self.param_groups) != 1:
+            return None
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            return None
+        flat_g, sig = getattr(m, "_dudf_flat_grad", None), getattr(m, "_dudf_flat_grad_sig", None)
+        if flat_g is None or sig is None:
+            return None
+        theta = m.flat_parameters()
+        params = g["params"]
+        if theta.device.type != "cuda" or len(params) != len(sig) or flat_g.numel() < theta.numel():
+            return None
+        mine = list(m.parameters())
+        if len(mine) != len(params) or any(a is not b for a, b in zip(mine, params)):
+            return None
+        for p, (ptr, stride) in zip(params, sig):
+            if p.grad is None or p.grad.data_ptr() != ptr or p.grad.stride() != stride:
+                return None
+        return theta, flat_g[:theta.numel()]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        fv = self._flat_views() if closure is None else None
+        if fv is None:
+            if self._t > 0 and not self._fell_back:
+                raise RuntimeError("diffudf_amd.optim.Adam: the flat parameter / gradient layout changed after the first "
+                                   "step; its moments cannot follow")
+            self._fell_back = True
+            return super().step(closure)
+        theta, dtheta = fv
+        if self._m is None:
+            self._m, self._v = torch.zeros_like(theta), torch.zeros_like(theta)
+        g = self.param_groups[0]
+        self._t += 1
+        hip_ops.adam_step(theta, dtheta, self._m, self._v, self._t, g["lr"], g["betas"][0], g["betas"][1], g["eps"])
+        return None

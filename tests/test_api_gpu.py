@@ -439,3 +439,39 @@ def test_any_hidden_layer_config(hidden):
     m2.load_state_dict(model.state_dict())
     y2 = m2(xd)["model_out"]
     assert torch.equal(y2, model(xd)["model_out"])
+
+
+def test_flat_adam_matches_torch_adam():
+    """diffudf_amd.optim.Adam (train.py's optimizer): with the flat parameter / gradient layout of train.py::_zero_flat_grad its
+    step() is ONE dudf_adam_step launch; it must follow torch.optim.Adam on the same gradients, and it must BE torch's Adam
+    (fallback) when the layout is not there."""
+    import train
+    from diffudf_amd.optim import Adam
+    torch.manual_seed(0)
+    a, _ = make_model([256] * 3, 7)
+    b, _ = make_model([256] * 3, 7)
+    oa = Adam(a.parameters(), lr=1e-3, model=a)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3)
+    for it in range(6):
+        flat = train._zero_flat_grad(a)
+        g = torch.randn(flat.numel() - 4, device="cuda:0") * (10.0 ** (it - 3))
+        flat[:-4] = g
+        for p, v in zip(b.parameters(), b.split_flat(g.clone())):
+            p.grad = v.clone()
+        if it == 3:
+            for grp in oa.param_groups + ob.param_groups:
+                grp["lr"] = 3e-4                                   # the loop edits param_groups between steps
+        oa.step(); ob.step()
+    assert oa._t == 6 and not oa._fell_back and len(oa.state) == 0      # the fast path ran
+    ta, tb = a.flat_parameters().double().cpu().numpy(), b.flat_parameters().double().cpu().numpy()
+    assert rel(ta, tb) < 5e-7
+    # no flat gradient buffer behind the .grads: plain torch.optim.Adam behaviour
+    c, _ = make_model([256] * 3, 7)
+    d, _ = make_model([256] * 3, 7)
+    oc = Adam(c.parameters(), lr=1e-3, model=c)
+    od = torch.optim.Adam(d.parameters(), lr=1e-3)
+    for p, q in zip(c.parameters(), d.parameters()):
+        p.grad = torch.ones_like(p); q.grad = torch.ones_like(q)
+    oc.step(); od.step()
+    assert oc._fell_back and len(oc.state) > 0
+    assert np.array_equal(c.flat_parameters().cpu().numpy(), d.flat_parameters().cpu().numpy())

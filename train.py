@@ -12,8 +12,8 @@ phase schedule (warm-up LR, lr_s1 from `warmup_epochs`, loss_s2 + cosine LR from
 `model_best.pth` / `model_current.pth` / `model_final.pth` with reference state_dict keys.
 
 What runs underneath is the MI355X path: the loss dict comes from the fused HIP kernels
-(diffudf_amd.loss_functions), the optimizer is torch.optim.Adam over the model's parameters (views of one flat
-buffer), and under torch.distributed every rank takes its stratified share of the batch and the gradients
+(diffudf_amd.loss_functions), the optimizer is diffudf_amd.optim.Adam — torch.optim.Adam whose step() is ONE launch over the
+flat parameter / gradient buffers the model's tensors are views of —, and under torch.distributed every rank takes its stratified share of the batch and the gradients
 are all-reduced over RCCL before the step.
 
 After training (reference train.py:403-446): the field slice of the best model (`generate_df`, always, as in the
@@ -37,6 +37,7 @@ import torch
 from diffudf_amd.dataset import PointCloud, SyntheticPointCloud
 from diffudf_amd.loss_functions import loss_siren, loss_s1, loss_s2
 from diffudf_amd.model import SIREN
+from diffudf_amd.optim import Adam
 from diffudf_amd.util import create_output_paths, load_experiment_parameters
 
 try:                                                  # optional, as in many deployments
@@ -274,7 +275,7 @@ def setup_train(parameter_dict, cuda_device):
     if opt_params["type"] != "adam":
         raise ValueError('Unknown optimizer')
     if gt_mode == 'tanh':
-        optimizer = torch.optim.Adam(lr=opt_params["lr_s1"], params=model.parameters())
+        optimizer = Adam(lr=opt_params["lr_s1"], params=model.parameters(), model=model)
         config_dict = {
             "epochs": parameter_dict["num_epochs"], "s1_epochs": parameter_dict["s1_epochs"],
             "warmup_epochs": parameter_dict.get("warmup_epochs", 0), "warmup_lr": parameter_dict.get("warmup_lr", 1e-4),
@@ -287,7 +288,7 @@ def setup_train(parameter_dict, cuda_device):
         }
         losses, best_weights, training_time = train_model_tanh(dataset, model, device, config_dict)
     elif gt_mode == 'siren':
-        optimizer = torch.optim.Adam(lr=opt_params["lr"], params=model.parameters())
+        optimizer = Adam(lr=opt_params["lr"], params=model.parameters(), model=model)
         config_dict = {
             "epochs": parameter_dict["num_epochs"], "batch_size": parameter_dict["batch_size"],
             "epochs_to_checkpoint": parameter_dict["epochs_to_checkpoint"], "gt_mode": gt_mode, "log_path": full_path,
