@@ -638,7 +638,12 @@ int dudf_launch_loss_fwd(const DudfLayout& lo, int mode, const float* normals, c
     // (the four sums and the ticket behind them were zeroed by the forward's prep kernel, dudf_launch_prep)
     a.out_terms = out_terms; a.inv_nd = 1.0 / (double)n_global;
     for (int i = 0; i < 4; ++i) a.wd[i] = w[i];
-    const int grid = dudf_deterministic() ? 1 : grid_for(lo.n);        // one block: one fixed summation order
+    // deterministic mode: one block = one fixed summation order.  Otherwise every block ends in four fp64 atomics on the SAME
+    // four addresses: at 391 blocks (100 000 points) the kernel spent 30 us queueing them; without the Hessian term a point
+    // costs a few dozen flops, so 128 blocks with a grid-stride loop finish sooner.  (With it — an fp64 Jacobi eigensolve per
+    // on-surface point — the work dominates: as many blocks as there are points for.)
+    int grid = dudf_deterministic() ? 1 : grid_for(lo.n);
+    if (!dudf_deterministic() && !(mode == DUDF_LOSS_S1 && w[2] != 0.0 && lo.n_h > 0) && grid > 128) grid = 128;
     if (mode == DUDF_LOSS_S1) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_S1>, dim3(grid), dim3(256), 0, st, a);
     else if (mode == DUDF_LOSS_SIREN) hipLaunchKernelGGL(loss_fwd_kernel<DUDF_LOSS_SIREN>, dim3(grid), dim3(256), 0, st, a);
     else return DUDF_E_BADMODE;
