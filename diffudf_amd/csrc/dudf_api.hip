@@ -577,7 +577,7 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
     const DudfLayout& lo = c.lo;
     const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
     if (which < 0 || which > 7) return DUDF_E_BADMODE;
-    return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st);
+    return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st, which == 1);   // C: one copy per quad
 }
 
 int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, int64_t* out) {

@@ -187,7 +187,7 @@ int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, doub
 int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms, hipStream_t st);
 int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
                      double eps, int64_t step, double gscale, hipStream_t st);
-int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st);
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st, int per_quad = 0);
 int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st);
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, float* out_h,
                          hipStream_t st);

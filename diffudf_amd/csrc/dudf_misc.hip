@@ -371,11 +371,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, co
 
 __global__ __launch_bounds__(256) void read_stash_kernel(const float* __restrict__ src, float* __restrict__ out,
                                                          int64_t n, int64_t n_h, int64_t ncol_h, int64_t np, int H,
-                                                         int channel) {
+                                                         int channel, int per_quad) {
     const int64_t tot = n * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / H; const int f = (int)(i % H);
-        const int64_t c = p < n_h ? 4 * p + channel : ncol_h + (p - n_h);
+        // Hessian-path points: four columns (channels) per point — except in C, which keeps one copy per quad (LaneOff)
+        const int64_t c = p < n_h ? (per_quad ? p : 4 * p + channel) : ncol_h + (p - n_h);
         out[i] = src[((int64_t)(f >> 2) * np + c) * 4 + (f & 3)];
     }
 }
@@ -690,9 +691,9 @@ int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n
     return (int)hipGetLastError();
 }
 
-int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st) {
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st, int per_quad) {
     hipLaunchKernelGGL(read_stash_kernel, dim3(grid_for(lo.n * lo.H)), dim3(256), 0, st,
-                       src + (int64_t)layer * lo.stash_layer, out, lo.n, lo.n_h, lo.ncol_h, lo.np, lo.H, channel);
+                       src + (int64_t)layer * lo.stash_layer, out, lo.n, lo.n_h, lo.ncol_h, lo.np, lo.H, channel, per_quad);
     return (int)hipGetLastError();
 }
 

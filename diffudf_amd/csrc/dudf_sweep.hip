@@ -133,6 +133,7 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
             return (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
         };
         const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);          // this lane's granule, in bytes
+        const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo);   // C: one copy per quad
 
         // every wave of the workgroup is past its last LDS read of the previous tile before buffers are refilled
         __syncthreads();
@@ -151,14 +152,14 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
             for (int T = 0; T < G::NT; ++T) {
                 const int64_t ub = stash_base(l0, T);
                 f32x4 o1, o2, o3, acc;
-                epilogue_loads<SW, FL>(a, ub, vo, o1, o2, o3);
+                epilogue_loads<SW, FL>(a, ub, vl, o1, o2, o3);
                 if constexpr (kFwdDir) {
                     acc = mfma16(a.w1b[(16 * T + li) * 4 + q], b, f32x4{0, 0, 0, 0});
                 } else {
                     acc = *reinterpret_cast<const f32x4*>(a.theta + a.off_wo + 16 * T + 4 * q) * yb;
                 }
                 if (T < G::NT - 2) {
-                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, o3, ub, vo, isv, tmax);
+                    in[T] = epilogue<SW, FL>(a, acc, o1, o2, o3, ub, vl, isv, tmax);
                 } else if (T == G::NT - 2) {
                     pend.acc0 = acc; pend.o1a = o1; pend.o2a = o2; pend.o3a = o3; pend.ub0 = ub;
                 } else {
@@ -213,8 +214,8 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
                     float* nbuf = lds + ((gc + 1) & 1) * G::BUF;
                     if (r + 1 < G::NCH) stage_issue<H>(M, r + 1, nbuf, stg, tid);
                     else if (Mn) stage_issue<H>(Mn, 0, nbuf, stg, tid);
-                    epilogue_loads<SW, FL>(a, cur.ub0, vo, cur.o1a, cur.o2a, cur.o3a);
-                    epilogue_loads<SW, FL>(a, cur.ub1, vo, cur.o1b, cur.o2b, cur.o3b);
+                    epilogue_loads<SW, FL>(a, cur.ub0, vl, cur.o1a, cur.o2a, cur.o3a);
+                    epilogue_loads<SW, FL>(a, cur.ub1, vl, cur.o1b, cur.o2b, cur.o3b);
                     if constexpr (BS == SWEEP_FWD) {
                         const float* bias = (r + 1 < G::NCH) ? M + (size_t)H * H + 32 * (r + 1)
                                                              : (Mn ? Mn + (size_t)H * H : M + (size_t)H * H);
@@ -225,8 +226,8 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
                     // freely interleavable region
                     __builtin_amdgcn_sched_barrier(0);
                     // tail of the previous chunk's two tiles (the previous layer's last two when r == 0)
-                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv, tmax);
-                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv, tmax);
+                    const f32x4 e0 = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vl, isv, tmax);
+                    const f32x4 e1 = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vl, isv, tmax);
                     if (r == 0) { in[G::NT - 2] = e0; in[G::NT - 1] = e1; }
                     else { nxt[2 * r - 2] = e0; nxt[2 * r - 1] = e1; }
                 };
@@ -263,8 +264,8 @@ __device__ __forceinline__ void sweep_tile(const SweepArgs& a, const int tile, f
             for (int T = 0; T < G::NT - 2; ++T) in[T] = nxt[T];
         }
         // flush the last pending pair
-        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vo, isv, tmax);
-        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vo, isv, tmax);
+        in[G::NT - 2] = epilogue<SW, FL>(a, pend.acc0, pend.o1a, pend.o2a, pend.o3a, pend.ub0, vl, isv, tmax);
+        in[G::NT - 1] = epilogue<SW, FL>(a, pend.acc1, pend.o1b, pend.o2b, pend.o3b, pend.ub1, vl, isv, tmax);
 
         // ------------------------------ tail ------------------------------
         if constexpr (BS == SWEEP_FWD) {                // y = W_out h_L + b_out (tangent channels: their own dot, unused)

@@ -341,9 +341,10 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
     const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);     // this lane's granule, in bytes
+    const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo);   // C: one copy per quad
     auto load_ops = [&](int layer, int kb, TailOps& o) {
-        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vo, o.o1a, o.o2a, o.o3a);
-        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vo, o.o1b, o.o2b, o.o3b);
+        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vl, o.o1a, o.o2a, o.o3a);
+        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vl, o.o1b, o.o2b, o.o3b);
         if constexpr (BS == SWEEP_FWD && SP != 0) {
             // fp16x3: every layer's bias sits in LDS behind the weight buffers (sweep_body_b) — a vector-memory instruction
             // costs its wave ~100 cycles of issue when the CU's eight waves contend (s_memtime timeline: the two bias loads
@@ -361,23 +362,23 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         const f32x4 zero = {0, 0, 0, 0};
         if constexpr (BS == SWEEP_FWD && SP != 0 && HS) {   // quads: the bias only in the value channel; `unscale` is this column's
             const f32x4 us = {unscale, unscale, unscale, unscale};
-            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
-            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
-            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
-            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
-            e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vo, isv, tmax);
-            e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+            e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (kColScale) {            // accumulators -> true values first (2^-k_j / sb of the matrix that made them)
-            e0 = epilogue<SW, FL, kTrackE>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv, tmax);
+            e0 = epilogue<SW, FL, kTrackE>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
 #if DUDF_TAILSEQ
             if constexpr (BS == SWEEP_ADJ_FWD) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the pair's temporaries do not fit
 #endif
-            e1 = epilogue<SW, FL, kTrackE>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+            e1 = epilogue<SW, FL, kTrackE>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else {
-            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vo, isv, tmax);
-            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vo, isv, tmax);
+            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         }
     };
     auto pin_ops = [&](TailOps& o) {                    // make the compiler wait for these loads HERE
@@ -625,13 +626,13 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                     if (kb + 1 < G::NKB && ((TA1 >= T && TA1 <= Tl && !late) || (TB1 >= T && TB1 <= Tl && late))) {
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("" : "+v"(ops_cur.o1a), "+v"(ops_cur.o2a));
-                        te0 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 2] * unscale, ops_cur.o1a, ops_cur.o2a, ops_cur.o3a, stash_base(lin, 2 * kb + 2), vo, isv, tmax);
+                        te0 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 2] * unscale, ops_cur.o1a, ops_cur.o2a, ops_cur.o3a, stash_base(lin, 2 * kb + 2), vl, isv, tmax);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (kb + 1 < G::NKB && ((TA2 >= T && TA2 <= Tl && !late) || (TB2 >= T && TB2 <= Tl && late))) {
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("" : "+v"(ops_cur.o1b), "+v"(ops_cur.o2b));
-                        const f32x4 te1 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 3] * unscale, ops_cur.o1b, ops_cur.o2b, ops_cur.o3b, stash_base(lin, 2 * kb + 3), vo, isv, tmax);
+                        const f32x4 te1 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 3] * unscale, ops_cur.o1b, ops_cur.o2b, ops_cur.o3b, stash_base(lin, 2 * kb + 3), vl, isv, tmax);
                         split(te0, te1, nb);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1363,6 +1364,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
     const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);
+    const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo);   // C: one copy per quad
     const int total2 = nhid * G::NKB * 2;
     auto chunk_src = [&](int c2) -> const char* {       // c2 = (matrix, k-block, half), wave-uniform
         const int j = c2 / (G::NKB * 2);
@@ -1409,7 +1411,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         constexpr int PD = (BS == SWEEP_FWD) ? 2 : ((SW == SWEEP_ADJ_FWD_H || SW == SWEEP_ADJ_REV_H) ? 4 : 8);
         f32x4 o1[PD], o2[PD], o3[PD], bs[PD];
         auto ld = [&](int T, int s) {
-            epilogue_loads<SW, FL>(a, stash_base(layer, T), vo, o1[s], o2[s], o3[s]);
+            epilogue_loads<SW, FL>(a, stash_base(layer, T), vl, o1[s], o2[s], o3[s]);
             if constexpr (BS == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
         };
         float cmax = 0.f;                              // fp16x3: largest |output| of this lane's rows of the column
@@ -1424,7 +1426,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             else if constexpr (SW == SWEEP_FWD) z += bs[s];
             else if constexpr (BS == SWEEP_FWD) z = (SP != 0 ? z * unscale : z) + (isv ? bs[s] : zero4);   // the bias: value channel only
             else if constexpr (SP != 0) z *= unscale;
-            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vo, isv, tmax);
+            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
             if constexpr (wide_relay_store<SW, FL>()) DUDF_ST(a.S, stash_base(layer, T), vo, e);
             if constexpr (kColScale) dudf_track(cmax, e);
             if (T + PD < G::NT) ld(T + PD, s);

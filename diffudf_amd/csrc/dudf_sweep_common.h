@@ -167,9 +167,20 @@ __device__ __forceinline__ void dudf_track(float& tmax, const f32x4 v) {
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(tmax) : "v"(v[2]), "v"(v[3]));
 }
 
+// A lane's byte offset into a stash array: `v` for every array, `c` for C.  They differ in the Hessian-quad columns only: cos(w0 z_l)
+// is the same number in all four channels of a quad (it is the VALUE channel's), so C keeps ONE copy per quad — at column
+// (p >> 2) of the quad region, written and read by all four lanes (same bits, same granule: one 16-byte access serves four lanes) —
+// instead of four: 3 of the quad sweeps' 16 stash units per column gone.
+struct LaneOff {
+    unsigned v, c;
+    __device__ __forceinline__ LaneOff(unsigned x) : v(x), c(x) {}
+    __device__ __forceinline__ LaneOff(unsigned x, unsigned y) : v(x), c(y) {}
+};
+
 template <int SW, int FL, bool TE = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
-                                          unsigned vo, bool isv, TailTrack& tk) {
+                                          const LaneOff lo, bool isv, TailTrack& tk) {
+    const unsigned vo = lo.v;
     f32x4 out;
     if constexpr (SW == SWEEP_FWD) {
         f32x4 s, c;
@@ -207,7 +218,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             zs[t] = isv ? sv : acc[t];
             out[t] = isv ? sv : a.w0 * cv * acc[t];
         }
-        DUDF_ST(a.C, ub, vo, c);
+        DUDF_ST(a.C, ub, lo.c, c);   // one copy per quad (LaneOff): the four lanes hold the same bits and write the same granule — no branch
         DUDF_ST(a.ZS, ub, vo, zs);
         if constexpr (FL & 1) DUDF_ST(a.S, ub, vo, out);
     } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
@@ -270,9 +281,10 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
 }
 
 template <int SW, int FL>
-__device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, unsigned vo, f32x4& o1, f32x4& o2,
+__device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, const LaneOff lo, f32x4& o1, f32x4& o2,
                                                f32x4& o3) {
     o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
+    const unsigned vo = lo.v;
     if constexpr (SW == SWEEP_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
         if constexpr (FL & 1) o2 = DUDF_LD(a.S, ub, vo);
@@ -283,14 +295,14 @@ __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, u
         o1 = DUDF_LD(a.C, ub, vo);
         if constexpr (FL & 1) o2 = DUDF_LD(a.E, ub, vo);            // no df/dx terms (loss_s2): e_l == 0
     } else if constexpr (SW == SWEEP_REV_H) {
-        o1 = DUDF_LD(a.C, ub, vo);
+        o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
-        o1 = DUDF_LD(a.C, ub, vo);
+        o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
         o3 = DUDF_LD(a.R, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_REV_H) {
-        o1 = DUDF_LD(a.C, ub, vo);
+        o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
         o3 = DUDF_LD(a.E, ub, vo);
     }
