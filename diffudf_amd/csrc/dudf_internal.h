@@ -99,8 +99,8 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_amax = take(4 * (int64_t)L);
     lo->ws_ebound = query_only ? lo->ws_amax : take((int64_t)L * lo->np);   // [L][np]: max_f |e_l[f][column]| (fp16x3 adjoint reverse sweep)
     // [L][np]: max_f |zdot_l[f][column]| of the tangent columns of the Hessian quads (left by the fp16x3 forward sweep of the
-    // quads for the column scales of the three sweeps behind it); only a training batch with Hessian-path points has it
-    lo->ws_zbound = (query_only || n_h == 0) ? lo->ws_amax : take((int64_t)L * lo->ncol_h);
+    // quads for the column scales of the sweeps behind it); every workspace with Hessian-path points has it (training and queries)
+    lo->ws_zbound = (n_h == 0) ? lo->ws_amax : take((int64_t)L * lo->ncol_h);
     lo->ws_x4 = take(4 * lo->np);
     lo->ws_y = take(lo->np); lo->ws_g = take(4 * lo->np);
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);

@@ -1241,18 +1241,18 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         }
         if (done) return (int)hipGetLastError();
     }
-    // ... and the Hessian quads' training sweeps (bit 5, DUDF_SPLIT_QUADS; queries and jets stay on bf16x6).  All four or none:
+    // ... and the Hessian quads' sweeps (bit 5, DUDF_SPLIT_QUADS; the jets stay on bf16x6).  All of a workspace's or none:
     // the forward sweep leaves zbound for the other three, the adjoint forward sweep ebound for the adjoint reverse one.
-    if (which >= SWEEP_FWD_H && which <= SWEEP_ADJ_REV_H && (a.split & 32) && a.zbound && a.ebound && a.L <= kMaxLdsBiasLayers) {
+    if (which >= SWEEP_FWD_H && which <= SWEEP_ADJ_REV_H && (a.split & 32) && a.zbound && a.L <= kMaxLdsBiasLayers) {
         constexpr size_t w3 = 3 * GeoB<H, 1>::CHUNKB;
         const size_t smem_q = w3 + kMaxAmaxLayers * sizeof(unsigned);
         const size_t smem_fq = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         constexpr size_t smem_fqmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         bool done = true;
-        if (which == SWEEP_FWD_H && a.store_s) DUDF_GO_H(SWEEP_FWD_H, 1, sweep_f16_np_kernel, smem_fqmax, smem_fq);
-        else if (which == SWEEP_REV_H && a.train) DUDF_GO_H(SWEEP_REV_H, 1, sweep_f16_np_kernel, smem_q, smem_q);
-        else if (which == SWEEP_ADJ_FWD_H) DUDF_GO_H(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
-        else if (which == SWEEP_ADJ_REV_H) DUDF_GO_H(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
+        if (which == SWEEP_FWD_H) { if (a.store_s) DUDF_GO_H(SWEEP_FWD_H, 1, sweep_f16_np_kernel, smem_fqmax, smem_fq); else DUDF_GO_H(SWEEP_FWD_H, 0, sweep_f16_np_kernel, smem_fqmax, smem_fq); }
+        else if (which == SWEEP_REV_H) { if (a.train) DUDF_GO_H(SWEEP_REV_H, 1, sweep_f16_np_kernel, smem_q, smem_q); else DUDF_GO_H(SWEEP_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q); }
+        else if (which == SWEEP_ADJ_FWD_H && a.ebound) DUDF_GO_H(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
+        else if (which == SWEEP_ADJ_REV_H && a.ebound) DUDF_GO_H(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
         else done = false;
         if (done) return (int)hipGetLastError();
     }
