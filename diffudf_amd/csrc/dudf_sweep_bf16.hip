@@ -236,7 +236,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                                              const bool stamp_on = false) {
     using G = GeoB<H, SP>;
     constexpr int NPC = G::NPC;
-    static_assert(SP == 0 || !is_jet(SW), "fp16x3: plain columns and Hessian quads");
+    static_assert(SP == 0 || SW <= SWEEP_FWD_J, "fp16x3: plain columns, Hessian quads, jets");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -293,6 +293,21 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     auto set_scale = [&](float amax_true, float extra, float zb) {
         float bound;
         if constexpr (!HS) { (void)zb; bound = a.w0 * amax_true + extra; }
+        else if constexpr (is_jet(SW)) {
+            // third-order jets: the tail of a monomial's column multiplies lower-order columns of the same point (epilogue,
+            // SWEEP_FWD_J) — the same combination, evaluated on the columns' maxima, bounds it (|sin|, |cos| <= 1)
+            const int l0 = lane & 48;
+            const unsigned jw = kJetLane[lane & 15];
+            const float w2 = 0.5f * (float)((jw >> 24) & 3), w3 = 0.5f * (float)((jw >> 26) & 3);
+            const float F[3] = {a.w0 * __shfl(amax_true, l0 + 1), a.w0 * __shfl(amax_true, l0 + 2), a.w0 * __shfl(amax_true, l0 + 3)};
+            auto sel = [&](unsigned k) -> float { k &= 3; return k == 0 ? F[0] : (k == 1 ? F[1] : F[2]); };
+            const float S0 = a.w0 * __shfl(amax_true, l0 + (int)(jw & 15)), S1 = a.w0 * __shfl(amax_true, l0 + (int)((jw >> 4) & 15)),
+                        S2 = a.w0 * __shfl(amax_true, l0 + (int)((jw >> 8) & 15));
+            const float fab = sel(jw >> 18) * sel(jw >> 20);
+            const float p2 = S0 * sel(jw >> 12) + S1 * sel(jw >> 14) + S2 * sel(jw >> 16) + w2 * fab;
+            const float p3 = w3 * fab * sel(jw >> 22);
+            bound = ((jw >> 28) & 1) ? 1.f : a.w0 * amax_true + p3 + p2;
+        }
         else if constexpr (BS == SWEEP_FWD) bound = isv ? 1.f : a.w0 * amax_true;
         else if constexpr (BS == SWEEP_REV) {
             const float av = quad_bcast0(amax_true);
@@ -315,7 +330,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         return 0.f;
     };
     auto store_zbound = [&](int layer, float m) {              // the quads' forward sweep leaves it (0 in the value columns)
-        if constexpr (kColScale && HS && BS == SWEEP_FWD) { if (q == 0) a.zbound[(int64_t)layer * a.nch + p] = isv ? 0.f : m; }
+        if constexpr (kColScale && HS && !is_jet(SW) && BS == SWEEP_FWD) { if (q == 0) a.zbound[(int64_t)layer * a.nch + p] = isv ? 0.f : m; }
     };
     float eb_next = 0.f, zb_next = 0.f;
     // running max |.| of what this sweep's tails store for the weight-gradient GEMM (q_l, A_l or zbar_l), per layer: lanes
@@ -1255,6 +1270,13 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         else if (which == SWEEP_ADJ_REV_H && a.ebound) DUDF_GO_H(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
         else done = false;
         if (done) return (int)hipGetLastError();
+    }
+    if (which == SWEEP_FWD_J && (a.split & 32) && a.L <= kMaxLdsBiasLayers) {      // the third-order jets (curvature query): nothing stashed
+        constexpr size_t w3 = 3 * GeoB<H, 1>::CHUNKB;
+        const size_t smem_j = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
+        constexpr size_t smem_jmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
+        DUDF_GO_H(SWEEP_FWD_J, 0, sweep_f16_np_kernel, smem_jmax, smem_j);
+        return (int)hipGetLastError();
     }
 #undef DUDF_GO_H
     switch (which) {
