@@ -14,16 +14,23 @@ six products) — fp32-equivalent, held to the fp32 parity tolerances.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--hidden H] [--no-cpu-baseline] [--no-config3]
 
 Prints ONE JSON line on rank 0.  Timing protocol: W untimed warm-up steps, then EXACTLY K steps between two
-barrier + synchronize pairs with the library's HIP-event profiler OFF; one event per step on the launch stream gives the
-per-step durations, and `value` is the batch size over their MEDIAN (`ms_per_step_mean` is the wall time
-between the barriers / K).  The per-kernel durations behind `roofline` come from a SEPARATE, untimed pass of a few steps
-with the profiler on (events on the launch stream, minus the measured cost of an empty event pair), together with the
-shader clock each kernel ran at (dudf_profile_clocks).
+barrier + synchronize pairs with the library's HIP-event profiler OFF; `value` = global batch x K / that wall time (MAX
+over ranks) and `ms_per_step` = wall time / K — the definition rounds 1 and 2 reported.  One event per step on the launch
+stream also gives the per-step durations: `ms_per_step_median` (what round 3 reported as `value`; the two differ by < 1 %).
+The per-kernel durations behind `roofline` come from a SEPARATE, untimed pass of a few steps with the profiler on (events
+on the launch stream, minus what an empty event pair reads; `kernel_times_sum_ms` is printed beside the step it belongs
+to), together with the shader clock each kernel ran at (dudf_profile_clocks) and the products per multiply of the kernel
+that was actually dispatched (dudf_profile_products).
+
+`--gpus N` with N > 1 and no torchrun environment: this file starts `python -m torch.distributed.run --nproc-per-node N`
+on itself as a CHILD process before anything touches the GPU, forwards its output and exits with its return code.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -158,7 +165,7 @@ class Runner:
             t = torch.tensor([el, med], dtype=torch.float64, device=self.dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             el, med = float(t[0]), float(t[1])
-        info = {"median_ms": med, "min_ms": per_step[0], "max_ms": per_step[-1], "kern": {}, "clocks_mhz": {}, "phases_ms": None,
+        info = {"median_ms": med, "min_ms": per_step[0], "max_ms": per_step[-1], "kern": {}, "clocks_mhz": {}, "products": {}, "phases_ms": None,
                 "event_cost_per_launch_ms": None,
                 "event_pair_overhead_ms": None, "profiled_step_ms": None, "collectives": getattr(eng, "collectives", None)}
         if profile_steps:
@@ -190,14 +197,18 @@ class Runner:
                 raw[name] = float(tot) / profile_steps
                 per_step[name] = int(cnt) / profile_steps
                 launches += int(cnt)
-            # what bracketing a launch with two events costs: an empty pair reads `ov`, but the events also serialise the
-            # stream — the profiled steps are slower than the timed ones by (profiled - timed) spread over the launches of a
-            # step.  The larger of the two is taken off every kernel's duration (so that the kernels of a step add up to at
-            # most the step they are part of; rocprofv3's own averages are in profiles/)
+            # An empty event pair reads `ov`: that much of every bracketed duration is the bracket itself and is taken off.
+            # Nothing else is: the events also serialise the stream a little (profiled steps run slower than timed ones),
+            # which is reported side by side (kernel_times_sum_ms vs ms_per_step, profiled_step_ms) instead of being
+            # subtracted — round 3 did, and it zeroed the four helper kernels and shaved 5 % off every sweep.
             prof_step = sorted(pm[i].elapsed_time(pm[i + 1]) for i in range(profile_steps))[profile_steps // 2]
-            per_launch = max(ov, (prof_step - med) / max(launches / profile_steps, 1.0)) if self.world == 1 else ov
+            per_launch = ov
             for name, v in raw.items():
                 info["kern"][name] = max(v - per_launch * per_step[name], 0.0)
+            self.lib.dudf_profile_products(buf, len(buf))
+            for line in buf.value.decode().splitlines():
+                name, prod = line.split()
+                info["products"][name] = int(prod)
             info["event_cost_per_launch_ms"] = per_launch
             self.lib.dudf_profile_clocks(buf, len(buf))
             for line in buf.value.decode().splitlines():
@@ -217,6 +228,12 @@ STASH_UNITS = {"sweep_fwd": (0, 2, "L"), "sweep_rev": (2, 2, "L"), "sweep_adj_fw
 SPLIT_BIT = {"sweep_fwd": 0, "sweep_rev": 1, "sweep_adj_fwd": 2, "sweep_adj_rev": 3, "wgrad_hidden": 4}
 
 
+def same_build(meta):
+    """Were the PMC files collected on the stash mode / split this run uses?  (a label check against counters of another
+    configuration would be meaningless; the A/B switches change what runs)"""
+    return not any(os.environ.get(v) for v in ("DUDF_SPLIT", "DUDF_SPLIT_SWEEPS", "DUDF_SWEEP", "DUDF_WGRAD", "DUDF_STASH"))
+
+
 def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
     """Every MFMA kernel against BOTH ceilings it could be bound by — the matrix pipe (executed MFMA flops = algorithmic
     flops x products per multiply of its operand split) and HBM (the stash bytes its dataflow moves) — and
@@ -227,16 +244,10 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
     hid = 2 * (layers - 1) * hidden * hidden                    # hidden x hidden matmul flops per point
     alg = {"sweep_fwd": F0, "sweep_rev": F0, "sweep_adj_fwd": F0, "sweep_adj_rev": F0,
            "wgrad_hidden": 2 * hid, "wgrad_small": 2 * (F0 - hid)}
-    # which matrix-core path a kernel takes: f32-input MFMA (1 executed flop per algorithmic flop, 157.3 TF), the exact
-    # three-piece bf16 split (6 products, 2.5 PF dense) or the fp16 hi/lo split (3 products, same pipe)
-    on16 = set()
-    if os.environ.get("DUDF_WGRAD", "bf16")[0] != "f":
-        on16.add("wgrad_hidden")
-    if hidden in (128, 256, 512) and layers >= 2 and os.environ.get("DUDF_SWEEP", "bf16")[0] != "f" and hip_ops.sweeps_on_bf16(hidden, layers):
-        on16 |= {"sweep_fwd", "sweep_rev", "sweep_adj_fwd", "sweep_adj_rev"}
-    mode = _lib.load().dudf_split_mode()
-    fp16_ok = {"sweep_fwd": hidden in (128, 256), "sweep_rev": hidden in (128, 256), "sweep_adj_fwd": hidden in (128, 256),
-               "sweep_adj_rev": hidden in (128, 256), "wgrad_hidden": hidden in (256, 512)}
+    # which matrix-core path a kernel took: the launchers record the products per algorithmic multiply of the kernel they
+    # dispatch (dudf_profile_products) — 1 = f32-input MFMA (157.3 TF), 6 = exact three-piece bf16 split, 3 = fp16 hi/lo split
+    # (both on the 2.5 PF dense 16-bit pipe).  Round 3 kept a table here and it went stale.
+    LABEL = {1: ("f32", PEAK_F32_MFMA_TFLOPS), 3: ("fp16x3", PEAK_BF16_MFMA_TFLOPS), 6: ("bf16x6", PEAK_BF16_MFMA_TFLOPS)}
     n_cols = points + 3 * n_hess                                 # columns the MFMA kernels process: 4 per Hessian-path point
     Lmap = {"L": layers, "L-1": layers - 1, "1": 1}
     per = {}
@@ -244,11 +255,8 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
         if k not in kern or kern[k] <= 0:
             continue
         tf = fl * n_cols / (kern[k] * 1e-3) / 1e12
-        if k in on16:
-            fp16 = bool((mode >> SPLIT_BIT.get(k, 31)) & 1) and fp16_ok.get(k, False) and (n_hess == 0 or bool(mode & 32))   # bit 5: the quads too
-            name, mult, peak = ("fp16x3", 3, PEAK_BF16_MFMA_TFLOPS) if fp16 else ("bf16x6", 6, PEAK_BF16_MFMA_TFLOPS)
-        else:
-            name, mult, peak = "f32", 1, PEAK_F32_MFMA_TFLOPS
+        mult = info["products"].get(k, 1)                        # wgrad_small: fp32 vector ALU, no matrix core
+        name, peak = LABEL[mult]
         rd, wr, lk = STASH_UNITS[k]
         sbytes = (rd + wr) * Lmap[lk] * hidden * 4 * n_cols
         tbs = sbytes / (kern[k] * 1e-3) / 1e12
@@ -273,6 +281,15 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
             traffic = tr.get(dom, {}).get("hbm_bytes_per_launch")
             tot = 0.0
             for k, d in per.items():
+                # the label against the counters: SQ_INSTS_MFMA x flops per instruction / algorithmic flops = products executed
+                mi = tr.get(k, {}).get("mfma_insts_per_launch")
+                if mi and d["mfma"] != "f32":
+                    flop_per_inst = 2 * 32 * 32 * 16 if k == "wgrad_hidden" else 2 * 16 * 16 * 32
+                    measured = mi * flop_per_inst / (alg[k] * n_cols)
+                    d["mfma_products_pmc"] = round(measured, 2)
+                    if same_build(meta) and abs(measured - {"fp16x3": 3, "bf16x6": 6}[d["mfma"]]) > 0.5:
+                        raise SystemExit(f"bench.py: {k} is labelled {d['mfma']} but the counters of {prof_json} show "
+                                         f"{measured:.2f} products per multiply")
                 b = tr.get(k, {}).get("hbm_bytes_per_launch")
                 if b:
                     d["hbm_bytes_per_launch"] = b
@@ -313,11 +330,33 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
                 "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k not in alg},
                 "kernel_times_sum_ms": round(sum(kern.values()), 4), "profiled_step_ms": info["profiled_step_ms"],
                 "event_pair_overhead_ms": info["event_pair_overhead_ms"], "event_cost_per_launch_ms": info["event_cost_per_launch_ms"],
+                "timed_step_ms": round(ms_step, 4),
                 "kernel_times_from": f"untimed pass of {PROFILE_STEPS} steps with HIP events on the launch stream (dudf_profile_*), "
-                                     "minus event_cost_per_launch_ms = max(what an empty event pair reads, (profiled step - timed "
-                                     "step) / launches per step); clock_mhz = shader clock over the lifetime of the kernel's first "
-                                     "workgroup (s_memtime / s_memrealtime)"})
+                                     "minus what an empty event pair reads (event_pair_overhead_ms) per launch — nothing else; "
+                                     "kernel_times_sum_ms belongs beside profiled_step_ms (the same pass) and timed_step_ms; "
+                                     "clock_mhz = shader clock over the lifetime of the kernel's first workgroup (s_memtime / "
+                                     "s_memrealtime); mfma = the split the dispatched kernel uses (dudf_profile_products)"})
     return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` as typed (N > 1, no torchrun environment): one rank per GPU through torch.distributed.run,
+    started as a CHILD process — never an exec — and before this process has made any GPU call (importing torch does not
+    initialise the device; asserted below and in tests/test_bench_launch.py).  The child's stdout (rank 0's one JSON line)
+    and stderr are inherited; the return value is the child's exit code."""
+    assert not torch.cuda.is_initialized(), "bench.py touched the GPU before spawning its ranks"
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if os.environ.get("DUDF_BENCH_DRY_LAUNCH") == "1":  # tests: show what would be started, start nothing
+        print(json.dumps({"launch": cmd, "cuda_initialized": torch.cuda.is_initialized()}))
+        return 0
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -335,13 +374,12 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary 8x512 / 125 000 points-per-GPU block")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N "
-                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -367,15 +405,15 @@ def main():
         # at other N).  Reported as a block of its own, never as `value`.
         s3 = max(10, args.steps // 4)
         el3, info3, loss3, ng3, _ = R.run(512, 8, 125000, s3, 3, "eikonal")
-        ms3 = info3["median_ms"]
+        ms3 = el3 / s3 * 1e3
         config3 = {"workload": f"SIREN 8x512 (w0=30), Eikonal loss_s1, 125000 synthetic points per GPU (global batch {ng3}; "
                                "BASELINE.json configs[2] at 8 GPUs), same step definition",
-                   "value": ng3 / (ms3 * 1e-3), "unit": "points/s", "ms_per_step": ms3, "ms_per_step_mean": el3 / s3 * 1e3,
+                   "value": ng3 / (ms3 * 1e-3), "unit": "points/s", "ms_per_step": ms3, "ms_per_step_median": info3["median_ms"],
                    "steps": s3, "n_gpus": world, "final_loss": loss3, "phases_ms": info3["phases_ms"],
                    "roofline": roofline_block(args, info3, 512, 8, 125000, 0, ms3) if rank == 0 else None}
 
     if rank == 0:
-        ms_step = info["median_ms"]
+        ms_step = el / args.steps * 1e3                 # wall time between the barriers / K, MAX over ranks
         value = n_global / (ms_step * 1e-3)
         weights = W_EIKONAL if args.loss == "eikonal" else [1e4, 1e4, 1e4, 1e3]
         out = {
@@ -384,10 +422,11 @@ def main():
             else f"train points/sec (SIREN fwd+∇x+{'Eikonal loss' if args.loss == 'eikonal' else 'Hessian+full loss_s1'}+bwd), "
                  f"{args.hidden}×{args.layers} net, {args.points} pts [secondary configuration]",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "ms_per_step_mean": el / args.steps * 1e3, "ms_per_step_min": info["min_ms"],
+            "ms_per_step": ms_step, "ms_per_step_median": info["median_ms"], "ms_per_step_min": info["min_ms"],
             "ms_per_step_max": info["max_ms"],
-            "timing_note": "value = global batch / MEDIAN step duration (one HIP event per step on the launch stream, MAX over "
-                           "ranks); ms_per_step_mean = wall time between the two barrier + synchronize pairs / steps",
+            "timing_note": "value = global batch x steps / wall time between the two barrier + synchronize pairs (MAX over "
+                           "ranks) — the mean, as in rounds 1-2; ms_per_step_median = median of the per-step durations (one "
+                           "HIP event per step on the launch stream), which is what round 3 reported as value",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 arithmetic throughout. The hidden-layer matmuls of the sweeps and the weight-gradient GEMM "

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DUDF_LIB") or os.path.join(_HERE, "libdudf_hip.so")
 LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
 
 _ERRORS = {
-    -1: "DUDF_E_BADCFG: unsupported network (equal hidden widths in {32,64,128,256,512}, n_in=3, n_out=1)",
+    -1: "DUDF_E_BADCFG: unsupported network (kernel width in {32,64,128,256,512} — hip_ops pads narrower / unequal layers —, n_in=3, n_out=1)",
     -2: "DUDF_E_WORKSPACE: workspace too small or misaligned",
     -3: "DUDF_E_BADMODE",
     -4: "DUDF_E_UNSUPPORTED: this configuration has no HIP path; there is deliberately no CPU fallback",
@@ -80,6 +80,8 @@ SYMBOLS = {
     "dudf_split_mode": (ctypes.c_int, []),
     "dudf_profile_dump": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "dudf_profile_clocks": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "dudf_profile_products": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "dudf_set_wgrad_max_workgroups": (ctypes.c_int, [ctypes.c_int]),
     "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int64, _P, _P, ctypes.c_size_t, _P]),
     "dudf_debug_stash_layout": (ctypes.c_int, [_CFG, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),

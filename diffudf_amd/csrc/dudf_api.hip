@@ -21,6 +21,10 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
+namespace { int g_products[PROF_NSLOTS] = {0}; int g_wgrad_maxwg = 256; }
+void dudf_note_products(int slot, int products) { if (slot >= 0 && slot < PROF_NSLOTS) g_products[slot] = products; }
+int dudf_wgrad_max_workgroups() { return g_wgrad_maxwg; }
+
 unsigned long long* dudf_prof_clk(int slot) { return (g_prof_on && g_prof_clk) ? g_prof_clk + 2 * slot : nullptr; }
 
 void dudf_prof_begin(int slot, hipStream_t st) {
@@ -543,6 +547,24 @@ int dudf_profile_clocks(char* buf, size_t buflen) {
         off += (size_t)w;
     }
     if (off < buflen) buf[off] = 0;
+    return 0;
+}
+
+int dudf_profile_products(char* buf, size_t buflen) {
+    size_t off = 0;
+    for (int i = 0; i < PROF_NSLOTS; ++i) {
+        if (!g_products[i]) continue;
+        int w = snprintf(buf + off, off < buflen ? buflen - off : 0, "%s %d\n", kProfNames[i], g_products[i]);
+        if (w < 0 || off + (size_t)w >= buflen) return DUDF_E_WORKSPACE;
+        off += (size_t)w;
+    }
+    if (off < buflen) buf[off] = 0;
+    return 0;
+}
+
+int dudf_set_wgrad_max_workgroups(int n) {
+    if (n < 8 || n > 256) return DUDF_E_BADCFG;
+    g_wgrad_maxwg = n;
     return 0;
 }
 

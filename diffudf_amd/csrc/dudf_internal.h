@@ -213,6 +213,11 @@ bool dudf_deterministic();
 // split (three products) where it is built.  Read once.
 bool dudf_split_fp16();
 int dudf_split_mask();
+// cap of the weight-gradient GEMM's grid (dudf_set_wgrad_max_workgroups in the C ABI; 256 = one workgroup per CU)
+int dudf_wgrad_max_workgroups();
+// products per algorithmic multiply of the kernel a launcher is about to start in profile slot `slot`: 1 = f32-input MFMA,
+// 3 = fp16 hi/lo split, 6 = three-piece bf16 split (bench.py labels and prices its roofline from THIS, not from a table)
+void dudf_note_products(int slot, int products);
 
 // ---- optional per-kernel HIP-event timing (dudf_profile_* in the C ABI) -----------------------------------
 enum { PROF_PACK = 0, PROF_SWEEP_FWD, PROF_SWEEP_REV, PROF_SWEEP_ADJ_FWD, PROF_SWEEP_ADJ_REV, PROF_WGRAD_HIDDEN,

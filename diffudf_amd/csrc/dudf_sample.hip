@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
             known = fabsf(off);
         }
     }
-    double best = 3.0e38, sbest = 1.7e19;               // sbest >= sqrt(best), refreshed whenever best improves
+    double best = 3.0e38, sbest = 1.8e19;               // sbest >= sqrt(best), refreshed whenever best improves
     const double dpx = px, dpy = py, dpz = pz;
     for (int64_t t0 = 0; t0 < a.n_tri; t0 += TRI_TILE) {
         const int cnt = (int)((a.n_tri - t0 < TRI_TILE) ? a.n_tri - t0 : TRI_TILE);

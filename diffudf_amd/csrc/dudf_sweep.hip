@@ -373,6 +373,7 @@ int launch_h(int which, const SweepArgs& a, hipStream_t st) {
 
 int dudf_launch_sweep(int which, int H, const SweepArgs& a, hipStream_t st) {
     DudfProfScope prof(PROF_SWEEP_FWD + (which & 3), st);
+    if (which <= SWEEP_ADJ_REV) dudf_note_products(PROF_SWEEP_FWD + which, 1);
     switch (H) {
         case 32: return launch_h<32>(which, a, st);
         case 64: return launch_h<64>(which, a, st);

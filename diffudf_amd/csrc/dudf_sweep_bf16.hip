@@ -1209,6 +1209,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     hipError_t e = hipSuccess;
 #define DUDF_GO_B(SW, FL)                                                                                   \
     do {                                                                                                    \
+        if (SW <= SWEEP_ADJ_REV) dudf_note_products(PROF_SWEEP_FWD + SW, 6);                                \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
             e = hipFuncSetAttribute(sweep_kernel_ptr<H, SW, FL>(),                                          \
@@ -1223,6 +1224,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
     } while (0)
 #define DUDF_GO_H(SW, FL, KERNEL, SMEM_MAX, SMEM)                                                           \
     do {                                                                                                    \
+        if (SW <= SWEEP_ADJ_REV) dudf_note_products(PROF_SWEEP_FWD + SW, 3);                                \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<H, SW, FL>),                      \
@@ -1661,6 +1663,7 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
     hipError_t e = hipSuccess;
 #define DUDF_GO_W(SW, FL)                                                                                   \
     do {                                                                                                    \
+        if (SW <= SWEEP_ADJ_REV) dudf_note_products(PROF_SWEEP_FWD + SW, 6);                                \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_w_kernel<SW, FL>),                 \
@@ -1672,6 +1675,7 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
     } while (0)
 #define DUDF_GO_W16(SW, FL)                                                                                 \
     do {                                                                                                    \
+        if (SW <= SWEEP_ADJ_REV) dudf_note_products(PROF_SWEEP_FWD + SW, 3);                                \
         static bool attr_done = false;                                                                      \
         const size_t smem16 = 3 * GeoWT<1>::CHUNKB + kMaxAmaxLayers * sizeof(unsigned);                     \
         if (!attr_done) {                                                                                   \
@@ -1772,6 +1776,7 @@ int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq0, const SweepArg
         nbp = 256 - nbq;
     }
     DudfProfScope prof(PROF_SWEEP_FWD + base, st);
+    dudf_note_products(PROF_SWEEP_FWD + base, 3);        // the plain columns of a pair launch are always fp16x3
     SweepArgs aq = aq0, ap = ap0;
     aq.clk = nullptr;
     ap.clk = dudf_prof_clk(PROF_SWEEP_FWD + base);

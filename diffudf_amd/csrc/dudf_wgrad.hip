@@ -963,10 +963,10 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     const int nl = a.nj;
     if (nl <= 0) return 0;
     const int tz = a.Hs / H, ntz = tz * tz;              // output tiles of a layer wider than the 256 x 256 tile
-    // one resident workgroup per CU, a single round.  DUDF_WGRAD_MAXWG (default 256) caps the grid: with more than one rank
-    // the engine sets 240, so that an RCCL kernel queued behind the previous layer group finds free CUs beside this GEMM
-    // (its workgroups fill the register file of the CUs they run on)
-    static const int maxwg = [] { const char* e = getenv("DUDF_WGRAD_MAXWG"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v : 256; }();
+    // one resident workgroup per CU, a single round.  dudf_set_wgrad_max_workgroups (default 256) caps the grid: with more
+    // than one rank the engine sets 240, so that an RCCL kernel queued behind the previous layer group finds free CUs
+    // beside this GEMM (its workgroups fill the register file of the CUs they run on)
+    const int maxwg = dudf_wgrad_max_workgroups();
     int nsplit = maxwg / (nl * ntz);
     if (nsplit > a.steps_total) nsplit = a.steps_total;
     if (nsplit < 1 || dudf_deterministic()) nsplit = 1;      // deterministic: one workgroup per weight tile, one add per element
@@ -979,6 +979,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     }
     // DUDF_WGRAD=f32 selects the f32-input MFMA kernel (A/B testing); default: bf16x6 at fp32 accuracy
     static const bool use_f32 = [] { const char* e = getenv("DUDF_WGRAD"); return e && e[0] == 'f'; }();
+    dudf_note_products(PROF_WGRAD_HIDDEN, use_f32 ? 1 : 6);         // (the fp16x3 branch below overrides)
     if (use_f32) {
         hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem, st, a);
     } else {
@@ -1005,6 +1006,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                 // order and the static-priority variants (round-2 experiments, measured no faster) are no longer built.
                 static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 9; }();
                 if (dudf_split_fp16() && a.amax && a.L <= 64 && var == 9) {       // fp16x3 (DUDF_SPLIT=bf16 keeps bf16x6)
+                    dudf_note_products(PROF_WGRAD_HIDDEN, 3);
                     static bool attr4 = false;
                     const size_t smem_h = 3 * (size_t)(2 * 2 * (H / 32) * 2 * (32 * 16 + 16)) + 512;   // three buffers x (X | Y) x 2 pieces + the flags
                     if (!attr4) {

@@ -60,10 +60,11 @@ class TrainEngine:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
-        if self.world > 1 and self.collectives == "staggered":
-            # leave 16 CUs to the RCCL kernels that overlap the weight-gradient GEMMs (read once by the library, at its
-            # first launch; a caller's own setting wins)
-            os.environ.setdefault("DUDF_WGRAD_MAXWG", "240")
+        if ops is None:
+            # staggered collectives: leave 16 CUs to the RCCL kernels that overlap the weight-gradient GEMMs; otherwise the
+            # whole chip.  An explicit setter of the C ABI: takes effect at the next launch, whatever ran before.
+            cap = 240 if (self.world > 1 and self.collectives == "staggered") else 256
+            self.ops.set_wgrad_max_workgroups(int(os.environ.get("DUDF_WGRAD_MAXWG", cap)))
 
     def _allreduce(self, t):
         if self.world > 1:

@@ -394,6 +394,11 @@ def fields_backward(cfg, theta, x, ybar, gbar, ws, dtheta=None, accumulate=False
     return dtheta
 
 
+def set_wgrad_max_workgroups(n):
+    """Cap of the weight-gradient GEMM's grid (8..256 workgroups): TrainEngine leaves CUs to overlapping RCCL kernels."""
+    _lib.check(_lib.load().dudf_set_wgrad_max_workgroups(int(n)), "dudf_set_wgrad_max_workgroups")
+
+
 def adam_step(theta, dtheta, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     lib = _lib.load()
     rc = lib.dudf_adam_step(_ptr(theta), _ptr(dtheta), _ptr(exp_avg), _ptr(exp_avg_sq), theta.numel(), float(lr),

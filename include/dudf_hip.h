@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define DUDF_E_BADCFG   (-1)   /* unsupported network shape (hidden widths must be equal, in {32,64,128,256,512}; 512: no Hessian path) */
+#define DUDF_E_BADCFG   (-1)   /* unsupported network shape: `hidden` must be one of {32,64,128,256,512} (the Python mirror pads any
+                                  list of widths <= 512 to the next built width with zero units, which is exact for a sine MLP) */
 #define DUDF_E_WORKSPACE (-2)  /* workspace too small / misaligned */
 #define DUDF_E_BADMODE  (-3)
 #define DUDF_E_UNSUPPORTED (-4)
@@ -237,6 +238,16 @@ int dudf_profile_dump(char* buf, size_t buflen);
  * s_memtime to the 100 MHz s_memrealtime over the lifetime of the kernel's first workgroup).  Every roofline fraction
  * depends on it: the nominal peaks assume 2.4 GHz. */
 int dudf_profile_clocks(char* buf, size_t buflen);
+/* "<kernel> <products>" per line: products per algorithmic multiply of the kernel the library last launched under that name —
+ * 1 = f32-input MFMA, 3 = fp16 hi/lo split ("fp16x3"), 6 = three-piece bf16 split ("bf16x6"); written by the launchers at the
+ * point of dispatch, so a roofline label cannot drift from what ran (bench.py multiplies its algorithmic flops with it). */
+int dudf_profile_products(char* buf, size_t buflen);
+
+/* Cap of the weight-gradient GEMM's grid, 8 .. 256 workgroups (default 256 = one per CU, a single resident round).  A
+ * multi-GPU step that overlaps its gradient all-reduces with the GEMM of the next layer group sets 240: the GEMM's workgroups
+ * fill the register file of the CUs they run on, and the RCCL kernel queued beside them needs CUs of its own
+ * (diffudf_amd/engine.py; replaces round 3's DUDF_WGRAD_MAXWG environment variable, which was read once at the first launch). */
+int dudf_set_wgrad_max_workgroups(int n);
 
 /* library / build identification, host string */
 const char* dudf_version(void);

@@ -278,11 +278,14 @@ def param_grad(params, x, cache, rev, ybar, gbar, w0=30.0, xp=np):
     return list(zip(dW, db)), trace
 
 
-def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, xp=np):
+def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, xp=np, want_trace=False):
     """Full SURVEY.md Appendix A.5: d(loss)/d(params) when the loss also depends on the Hessian
     (cotangent Hbar (N,3,3) on H[n,i,k] = d(df/dx_i)/dx_k), i.e. `backward()` through
     reference src/diff_operators.py:187-193 + torch.linalg.eigh (src/loss_functions.py:141-145).
-    `tang` is the second return value of `hessian()` (zd[k][l], ad[k][l])."""
+    `tang` is the second return value of `hessian()` (zd[k][l], ad[k][l]).
+    want_trace: also return the per-layer adjoints the parity tests compare a kernel's stash with — value channel
+    A[l], E[l] (= w0 c sbar_rev - w0 s cbar_rev; e_l of the plain path is its negative where the tangents vanish), zbar[l];
+    tangent channels Ad[k][l], Ed[k][l] (= zdotbar_rev), zdbar[k][l]."""
     L = len(params) - 1
     s, c = cache["s"], cache["c"]
     a = rev["a"]
@@ -305,6 +308,8 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
     Ap = gbar if gbar is not None else 0.0 * x
     Adp = [Hbar[:, :, k] for k in range(3)]
     cbar_rev, sbar_rev, zdbar_rev = [None] * L, [None] * L, [[None] * L for _ in range(3)]
+    tr = {"A": [None] * L, "Ad": [[None] * L for _ in range(3)], "E": [None] * L, "Ed": zdbar_rev, "zbar": [None] * L,
+          "zdbar": [[None] * L for _ in range(3)]}
     for l in range(L):
         W = params[l][0]
         Q = xp.matmul(Ap, W.T)
@@ -324,6 +329,10 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
         cbar_rev[l], sbar_rev[l] = cb, sb
         Adp = [w0 * c[l] * Qd[k] for k in range(3)]
         Ap = Anew
+        tr["A"][l] = Ap
+        tr["E"][l] = w0 * c[l] * sb - w0 * s[l] * cb
+        for k in range(3):
+            tr["Ad"][k][l] = Adp[k]
     dW[L] = dW[L] + Ap.sum(0)[None, :]
     # (ii) adjoint of the forward sweeps, backward in l
     Wo = params[-1][0]
@@ -339,6 +348,9 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
             cb = cb + w0 * zd[k][l] * hdbar[k]
         sb = sbar_rev[l] + hbar
         zbar = w0 * c[l] * sb - w0 * s[l] * cb
+        tr["zbar"][l] = zbar
+        for k in range(3):
+            tr["zdbar"][k][l] = zdbar[k]
         hprev = x if l == 0 else s[l - 1]
         dW[l] = dW[l] + xp.matmul(zbar.T, hprev)
         for k in range(3):
@@ -347,7 +359,7 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
         if l > 0:
             hbar = xp.matmul(zbar, W)
             hdbar = [xp.matmul(zdbar[k], W) for k in range(3)]
-    return list(zip(dW, db))
+    return (list(zip(dW, db)), tr) if want_trace else list(zip(dW, db))
 
 
 # --------------------------------------------------------------------------
@@ -381,8 +393,8 @@ def loss_and_grad(mode, params, x, normals, sdf, weights, alpha=100.0, w0=30.0, 
     else:
         raise ValueError(mode)
     if mode == "s1" and weights[2] != 0:
-        grads = param_grad_hessian(params, x, cache, rev, tang, cot["ybar"], cot.get("gbar"), cot["Hbar"], w0, xp)
-        trace = None
+        grads, trace = param_grad_hessian(params, x, cache, rev, tang, cot["ybar"], cot.get("gbar"), cot["Hbar"], w0, xp,
+                                          want_trace=True)
     else:
         grads, trace = param_grad(params, x, cache, rev, cot["ybar"], cot.get("gbar"), w0, xp)
     dbg = {"y": y, "g": g, "H": H, "tang": tang, "cache": cache, "rev": rev, "cot": cot, "trace": trace}
