@@ -222,9 +222,14 @@ class Runner:
         return el, info, final_loss, n_global, n_hess
 
 
-# stash traffic of each kernel in units of one [layer][H][column] fp32 array: (reads, writes, layers)
-STASH_UNITS = {"sweep_fwd": (0, 2, "L"), "sweep_rev": (2, 2, "L"), "sweep_adj_fwd": (2, 2, "L"), "sweep_adj_rev": (2, 1, "L"),
-               "wgrad_hidden": (4, 0, "L-1"), "wgrad_small": (4, 0, "1")}
+# stash traffic of each kernel in BYTES per (layer, feature, column) — DESIGN.md §3.2 — for the two stash formats
+# (dudf_stash_mode): 0 = every array fp32; 1 = the backward-only arrays S, Q, R, E, A, Z at 24 bits (3 bytes), C fp32.
+#   forward: writes S, C | reverse: reads C, S, writes Q, R | adjoint forward: reads C, R, writes A, E |
+#   adjoint reverse: reads C, E, writes Z | weight gradients: read Q, A, Z, S.                  (bytes read, bytes written, layers)
+STASH_BYTES = {0: {"sweep_fwd": (0, 8, "L"), "sweep_rev": (8, 8, "L"), "sweep_adj_fwd": (8, 8, "L"), "sweep_adj_rev": (8, 4, "L"),
+                   "wgrad_hidden": (16, 0, "L-1"), "wgrad_small": (16, 0, "1")},
+               1: {"sweep_fwd": (0, 7, "L"), "sweep_rev": (7, 6, "L"), "sweep_adj_fwd": (7, 6, "L"), "sweep_adj_rev": (7, 3, "L"),
+                   "wgrad_hidden": (12, 0, "L-1"), "wgrad_small": (12, 0, "1")}}
 SPLIT_BIT = {"sweep_fwd": 0, "sweep_rev": 1, "sweep_adj_fwd": 2, "sweep_adj_rev": 3, "wgrad_hidden": 4}
 
 
@@ -248,6 +253,7 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
     # dispatch (dudf_profile_products) — 1 = f32-input MFMA (157.3 TF), 6 = exact three-piece bf16 split, 3 = fp16 hi/lo split
     # (both on the 2.5 PF dense 16-bit pipe).  Round 3 kept a table here and it went stale.
     LABEL = {1: ("f32", PEAK_F32_MFMA_TFLOPS), 3: ("fp16x3", PEAK_BF16_MFMA_TFLOPS), 6: ("bf16x6", PEAK_BF16_MFMA_TFLOPS)}
+    stash_mode = max(hip_ops.stash_mode(hip_ops.make_cfg([hidden] * layers)), 0)
     n_cols = points + 3 * n_hess                                 # columns the MFMA kernels process: 4 per Hessian-path point
     Lmap = {"L": layers, "L-1": layers - 1, "1": 1}
     per = {}
@@ -257,8 +263,8 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
         tf = fl * n_cols / (kern[k] * 1e-3) / 1e12
         mult = info["products"].get(k, 1)                        # wgrad_small: fp32 vector ALU, no matrix core
         name, peak = LABEL[mult]
-        rd, wr, lk = STASH_UNITS[k]
-        sbytes = (rd + wr) * Lmap[lk] * hidden * 4 * n_cols
+        rd, wr, lk = STASH_BYTES[stash_mode][k]
+        sbytes = (rd + wr) * Lmap[lk] * hidden * n_cols
         tbs = sbytes / (kern[k] * 1e-3) / 1e12
         per[k] = {"avg_ms": round(kern[k], 4), "algorithmic_tflops": round(tf, 2), "mfma": name,
                   "executed_tflops": round(tf * mult, 2), "peak": peak, "frac": round(tf * mult / peak, 4),
@@ -311,12 +317,14 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
             traffic = None
     d = per[dom]
     hbm_bound = d["hbm_frac"] >= d["frac"]
-    out = {"kernel": dom, "mfma": d["mfma"], "clock_mhz": d["clock_mhz"], "traffic": traffic, "traffic_source": source}
+    out = {"kernel": dom, "mfma": d["mfma"], "clock_mhz": d["clock_mhz"], "traffic": traffic, "traffic_source": source,
+           "stash": {0: "fp32 (17 array-layer units of 4 bytes per value and column)",
+                     1: "24-bit backward-only arrays S, Q, R, E, A, Z (3 bytes per value, tile-major) + fp32 C: 13.75 units"}[stash_mode]}
     if hbm_bound:
         out.update({"bound": "hbm", "achieved": round(d["stash_tb_s"] * 1e3, 1), "peak": PEAK_HBM_TB_S * 1e3, "unit": "GB/s",
                     "frac": d["hbm_frac"], "algorithmic_bytes_per_launch": d["stash_bytes_per_launch"],
                     "note": "achieved = the stash bytes this kernel's dataflow moves per launch (DESIGN.md §3.2: reads + writes of "
-                            "[layer][H][column] fp32 arrays) / its launch duration; the same kernel against the matrix pipe: "
+                            "[layer][H][column] arrays, 4 or 3 bytes per value) / its launch duration; the same kernel against the matrix pipe: "
                             f"{d['executed_tflops']} of {d['peak']} TFLOP/s executed ({d['mfma']})"})
     else:
         out.update({"bound": "mfma", "achieved": d["executed_tflops"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],

@@ -85,6 +85,7 @@ SYMBOLS = {
     "dudf_debug_read_stash": (ctypes.c_int, [_CFG, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int64, _P, _P, ctypes.c_size_t, _P]),
     "dudf_debug_stash_layout": (ctypes.c_int, [_CFG, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
+    "dudf_stash_mode": (ctypes.c_int, [_CFG]),
 }
 
 

@@ -5,6 +5,10 @@
 #include <string.h>
 #include <vector>
 
+#ifndef DUDF_STASH_DEFAULT_P24
+#define DUDF_STASH_DEFAULT_P24 false
+#endif
+
 // ---- per-kernel HIP-event timing ---------------------------------------------------------------------------
 namespace {
 struct ProfRec { int slot; hipEvent_t e0, e1; };
@@ -67,6 +71,26 @@ bool use_bf16_sweeps() {
     return on;
 }
 
+}  // namespace
+
+// DUDF_STASH: "17" = every stash array fp32 (rounds 1-3), "17p24" = the backward-only arrays S, Q, R, E, A, Z at 24 bits,
+// tile-major (dudf_internal.h).  The 24-bit format exists in the fp16x3 training kernels of 256-wide networks and in the
+// cooperative-split weight-gradient GEMM; any A/B switch that routes a kernel elsewhere keeps the fp32 stash.
+bool dudf_stash_p24_enabled(int H, int L) {
+    static const bool want = [] {
+        const char* e = getenv("DUDF_STASH");
+        const bool on = e ? strstr(e, "p24") != nullptr : DUDF_STASH_DEFAULT_P24;
+        if (!on) return false;
+        const char* w = getenv("DUDF_WGRAD"); const char* v = getenv("DUDF_WGRAD_VAR");
+        if (w && w[0]) return false;                                        // f32 / bf16w weight-gradient kernels read fp32 rows
+        if (v && (atoi(v) & 15) != 9) return false;
+        return use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47 && !getenv("DUDF_LATE_FORCE");
+    }();
+    return want && H == 256 && L >= 2 && L <= 32;
+}
+
+namespace {
+
 int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
     if (!ws || bytes < lo.total_bytes || (reinterpret_cast<uintptr_t>(ws) & 255)) return DUDF_E_WORKSPACE;
     if (lo.np > (1ll << 25)) return DUDF_E_BADCFG;          // 32-bit lane BYTE offsets inside a stash layer (4 np granules of 16 B)
@@ -95,6 +119,7 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.L = lo.L; a.w0 = lo.w0;
     a.store_s = 0; a.store_c = 0; a.train = 0; a.have_e = 1;
     a.tile0 = 0; a.ntiles = 0; a.hess = 0;
+    a.p24 = lo.p24;
     static const int prio = [] { const char* e = getenv("DUDF_SWEEP_PRIO"); return e ? atoi(e) : 0; }();
     a.prio = prio;
     return a;
@@ -599,7 +624,8 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
     const DudfLayout& lo = c.lo;
     const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
     if (which < 0 || which > 7) return DUDF_E_BADMODE;
-    return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st, which == 1);   // C: one copy per quad
+    const bool b24 = lo.p24 && which != 1 && which != 7;          // S, Q, E, A, Z, R: 24-bit tile-major in a p24 workspace
+    return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st, which == 1, b24);   // C: one copy per quad
 }
 
 int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, int64_t* out) {
@@ -612,6 +638,12 @@ int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, 
     out[8] = lo.np * 16;                                  // bytes between two feature-quad rows
     out[9] = lo.stash_layer * (int64_t)sizeof(float);     // bytes between two layers
     return 0;
+}
+
+int dudf_stash_mode(const dudf_net_cfg* cfg) {
+    DudfLayout lo;
+    if (dudf_make_layout(cfg, 1, 0, &lo)) return -1;
+    return lo.p24 ? 1 : 0;
 }
 
 }  // extern "C"

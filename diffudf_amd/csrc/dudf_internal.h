@@ -46,8 +46,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //     R  r_l = w0^2 s_l a_l (plain)  |  a_l | adot_l^k (Hessian)          E  e_l (see dudf_sweep.hip)
 //     A  A_l   | Adot_l^k      (Y operand of wgrad)                        Z  zbar_l | zdotbar_l^k (X operand)
 //   acc: DUDF_NACC doubles of reduction scratch (loss sums, s2 statistics)
+//
+// "p24" stash (round 4; DudfLayout::p24, training workspaces of 256-wide networks whose sweeps and weight-gradient GEMM run
+// their fp16x3 kernels; DUDF_STASH=17 keeps everything fp32): the arrays that only the BACKWARD reads — S, Q, R, E, A, Z —
+// hold fp32 values rounded to 24 bits (sign, 8 exponent, 15 mantissa bits: relative error <= 2^-17), four values in 12
+// bytes; C (read by the reverse sweep, whose df/dx has no precision to spare) and ZS stay fp32.  A 12-byte granule per
+// lane makes 192-byte row segments, every second cache line shared by two waves: measured, partial-line writes give back
+// 15 of the 25 % (tools/micro/hbm_p24.hip, profiles/r04_hbm_p24.txt).  So these arrays are TILE-MAJOR instead:
+//     [layer][feature tile T = f/16][column group g = p/16][lane = 16*((f%16)/4) + p%16][3 dwords]
+// i.e. the 64 lanes of a wave write their accumulator tile as 768 contiguous bytes (six full lines):
+//     byte offset of granule (layer, f, p) = (((layer*(H/16) + f/16)*(np/16) + p/16)*64 + 16*((f%16)/4) + p%16)*12
+// dwords of a granule (values v0..v3 = features 4q..4q+3, u_i = bits(v_i) + 0x80):
+//     d0 = u0>>8 | u1.byte1<<24,  d1 = u1>>16 | (u2>>8)<<16,  d2 = u2.byte3 | (u3>>8)<<8
 struct DudfLayout {
     int H, L;
+    int p24;                 // 1: S, Q, R, E, A, Z are 24-bit tile-major arrays (see above)
     float w0;
     int64_t n, n_h;          // points, and how many of them (the first n_h) take the Hessian path
     int64_t ncol_h, ncol_n;  // padded column counts of the two ranges
@@ -58,9 +71,13 @@ struct DudfLayout {
     // workspace
     int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_ebound, ws_zbound, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
     int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
-    int64_t stash_layer;     // H*np: floats per layer in a stash array
+    int64_t stash_layer;     // H*np: floats per layer in a stash array (p24 arrays: 3/4 of that, H*np*3 BYTES)
     size_t total_bytes;
 };
+
+// 24-bit stash selected for this network?  (dudf_api.hip: DUDF_STASH, and every kernel of the step must be the fp16x3 build
+// that reads / writes it)
+bool dudf_stash_p24_enabled(int H, int L);
 
 static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo, int query_only = 0) {
     if (!cfg || cfg->n_in != 3 || cfg->n_hidden_layers < 1) return DUDF_E_BADCFG;
@@ -69,6 +86,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     if (n < 0 || n_h < 0 || n_h > n) return DUDF_E_BADCFG;
     lo->H = H; lo->L = L; lo->w0 = cfg->w0;
     lo->n = n; lo->n_h = n_h;
+    lo->p24 = (!query_only && dudf_stash_p24_enabled(H, L)) ? 1 : 0;
     auto pad = [](int64_t c) { return (c + DUDF_COL_PAD - 1) / DUDF_COL_PAD * DUDF_COL_PAD; };
     lo->ncol_h = pad(4 * n_h);
     lo->ncol_n = pad(n - n_h);
@@ -79,7 +97,8 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     // np * 16 bytes a large power of two would put all rows of a stash array on the same HBM channels (measured: 131 072
     // columns ran 1.9x slower per point than 98 304): skew the rows by one 256-byte granule.  (Skewing EVERY size — the row
     // stride is always a multiple of 2 KiB — was measured in round 3 and changes nothing at 100 000 points.)
-    if (lo->np % 2048 == 0) lo->np += 16;
+    if (lo->np % 2048 == 0) lo->np += 32;
+    if (lo->np * 1024 >= (1ll << 32)) lo->p24 = 0;            // 32-bit lane byte offsets inside a layer of a stash array (the weight-gradient GEMM's staging loads)
     lo->off_w1 = 0; lo->off_b1 = 3 * (int64_t)H;
     lo->off_hid = 4 * (int64_t)H; lo->hid_stride = (int64_t)H * H + H;
     lo->off_wo = lo->off_hid + (L - 1) * lo->hid_stride; lo->off_bo = lo->off_wo + H;
@@ -106,13 +125,14 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
     lo->stash_layer = (int64_t)H * lo->np;
     const int64_t stash = (int64_t)L * lo->stash_layer;
-    lo->ws_S = take(stash); lo->ws_C = take(stash);
+    const int64_t stash_b = lo->p24 ? stash / 4 * 3 : stash;       // the backward-only arrays: 12 instead of 16 bytes per granule
+    lo->ws_S = take(stash_b); lo->ws_C = take(stash);
     lo->ws_ZS = n_h > 0 ? take(stash) : lo->ws_S;
     if (query_only) {        // value / df/dx / Hessian queries only ever touch S, C, ZS: 16-24 KB per column instead of 56-64
         lo->ws_Q = lo->ws_R = lo->ws_E = lo->ws_A = lo->ws_Z = lo->ws_S;
     } else {
-        lo->ws_Q = take(stash); lo->ws_R = take(stash); lo->ws_E = take(stash); lo->ws_A = take(stash);
-        lo->ws_Z = take(stash);
+        lo->ws_Q = take(stash_b); lo->ws_R = take(stash_b); lo->ws_E = take(stash_b); lo->ws_A = take(stash_b);
+        lo->ws_Z = take(stash_b);
     }
     lo->ws_acc = take(2 * DUDF_NACC);
     lo->total_bytes = (size_t)o * sizeof(float);
@@ -152,6 +172,7 @@ struct SweepArgs {
     int store_s, store_c, train;   // what the sweep has to leave behind
     int have_e;                    // reverse adjoint sweep: e_l was produced by SWEEP_ADJ_FWD
     int prio;                      // bf16 sweeps: static priority for waves 0-3 of a workgroup (stagger of the SIMD partners)
+    int p24;                       // S, Q, R, E, A, Z are 24-bit tile-major arrays (DudfLayout::p24)
 };
 
 enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,
@@ -187,7 +208,7 @@ int dudf_launch_s2_stats(const DudfLayout& lo, const float* sdf, float* ws, doub
 int dudf_launch_s2_terms(const double* stats, const double* w, float* out_terms, hipStream_t st);
 int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
                      double eps, int64_t step, double gscale, hipStream_t st);
-int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st, int per_quad = 0);
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st, int per_quad = 0, int p24 = 0);
 int dudf_launch_copy_in(const DudfLayout& lo, const float* ybar, const float* gbar, float* ws, hipStream_t st);
 int dudf_launch_copy_out(const DudfLayout& lo, const float* ws, float* out_f, float* out_g, float* out_h,
                          hipStream_t st);

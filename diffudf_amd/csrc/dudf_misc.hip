@@ -371,13 +371,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, co
 
 __global__ __launch_bounds__(256) void read_stash_kernel(const float* __restrict__ src, float* __restrict__ out,
                                                          int64_t n, int64_t n_h, int64_t ncol_h, int64_t np, int H,
-                                                         int channel, int per_quad) {
+                                                         int channel, int per_quad, int p24) {
     const int64_t tot = n * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / H; const int f = (int)(i % H);
         // Hessian-path points: four columns (channels) per point — except in C, which keeps one copy per quad (LaneOff)
         const int64_t c = p < n_h ? (per_quad ? p : 4 * p + channel) : ncol_h + (p - n_h);
-        out[i] = src[((int64_t)(f >> 2) * np + c) * 4 + (f & 3)];
+        if (p24) {
+            // 24-bit tile-major array (dudf_internal.h): granule of (feature quad, column) = 3 dwords holding the top three
+            // bytes of four values; `src` already points at the layer (H * np * 3 bytes per layer)
+            const unsigned* g = reinterpret_cast<const unsigned*>(src) +
+                                ((((int64_t)(f >> 4) * (np >> 4) + (c >> 4)) * 64) + 16 * ((f & 15) >> 2) + (c & 15)) * 3;
+            const unsigned d0 = g[0], d1 = g[1], d2 = g[2];
+            const int e = f & 3;
+            const unsigned u = e == 0 ? d0 << 8 : e == 1 ? ((d0 >> 24) << 8) | (d1 << 16) : e == 2 ? ((d1 >> 16) << 8) | (d2 << 24) : d2 & 0xffffff00u;
+            out[i] = __uint_as_float(u);
+        } else {
+            out[i] = src[((int64_t)(f >> 2) * np + c) * 4 + (f & 3)];
+        }
     }
 }
 
@@ -691,9 +702,10 @@ int dudf_launch_adam(float* theta, const float* g, float* m, float* v, int64_t n
     return (int)hipGetLastError();
 }
 
-int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st, int per_quad) {
+int dudf_launch_read_stash(const DudfLayout& lo, const float* src, int layer, int channel, float* out, hipStream_t st, int per_quad, int p24) {
     hipLaunchKernelGGL(read_stash_kernel, dim3(grid_for(lo.n * lo.H)), dim3(256), 0, st,
-                       src + (int64_t)layer * lo.stash_layer, out, lo.n, lo.n_h, lo.ncol_h, lo.np, lo.H, channel, per_quad);
+                       src + (int64_t)layer * (p24 ? lo.stash_layer / 4 * 3 : lo.stash_layer), out, lo.n, lo.n_h, lo.ncol_h, lo.np, lo.H,
+                       channel, per_quad, p24);
     return (int)hipGetLastError();
 }
 

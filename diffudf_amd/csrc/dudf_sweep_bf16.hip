@@ -231,12 +231,13 @@ __device__ __forceinline__ unsigned amax_lds_off(const SweepArgs& a) {
 
 // One pass: the workgroup's waves 0..nact-1 take the 16-column groups g_first.. through a whole sweep.  Waves beyond
 // nact (the last, partial pass of a workgroup's share) only keep the weight stream and the barriers going.
-template <int H, int SW, int FL, int SP = 0>
+template <int H, int SW, int FL, int SP = 0, int P24 = 0>
 __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc,
                                              const bool stamp_on = false) {
     using G = GeoB<H, SP>;
     constexpr int NPC = G::NPC;
     static_assert(SP == 0 || SW <= SWEEP_FWD_J, "fp16x3: plain columns, Hessian quads, jets");
+    static_assert(P24 == 0 || (SP != 0 && H == 256 && !is_jet(SW)), "24-bit stash: the fp16x3 training kernels of 256-wide layers");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -356,10 +357,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
     const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);     // this lane's granule, in bytes
-    const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo);   // C: one copy per quad
+    const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo,   // C: one copy per quad
+                     P24 ? (unsigned)(((p >> 4) * 64 + lane) * 12) : 0u);                                         // 24-bit tile-major arrays
     auto load_ops = [&](int layer, int kb, TailOps& o) {
-        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb), vl, o.o1a, o.o2a, o.o3a);
-        epilogue_loads<SW, FL>(a, stash_base(layer, 2 * kb + 1), vl, o.o1b, o.o2b, o.o3b);
+        epilogue_loads<SW, FL, P24 != 0>(a, stash_base(layer, 2 * kb), vl, o.o1a, o.o2a, o.o3a);
+        epilogue_loads<SW, FL, P24 != 0>(a, stash_base(layer, 2 * kb + 1), vl, o.o1b, o.o2b, o.o3b);
         if constexpr (BS == SWEEP_FWD && SP != 0) {
             // fp16x3: every layer's bias sits in LDS behind the weight buffers (sweep_body_b) — a vector-memory instruction
             // costs its wave ~100 cycles of issue when the CU's eight waves contend (s_memtime timeline: the two bias loads
@@ -377,23 +379,23 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         const f32x4 zero = {0, 0, 0, 0};
         if constexpr (BS == SWEEP_FWD && SP != 0 && HS) {   // quads: the bias only in the value channel; `unscale` is this column's
             const f32x4 us = {unscale, unscale, unscale, unscale};
-            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
-            e0 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
-            e0 = epilogue<SW, FL>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24 != 0>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24 != 0>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (kColScale) {            // accumulators -> true values first (2^-k_j / sb of the matrix that made them)
-            e0 = epilogue<SW, FL, kTrackE>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e0 = epilogue<SW, FL, kTrackE, P24 != 0>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
 #if DUDF_TAILSEQ
             if constexpr (BS == SWEEP_ADJ_FWD) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the pair's temporaries do not fit
 #endif
-            e1 = epilogue<SW, FL, kTrackE>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e1 = epilogue<SW, FL, kTrackE, P24 != 0>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else {
-            e0 = epilogue<SW, FL>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24 != 0>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24 != 0>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         }
     };
     auto pin_ops = [&](TailOps& o) {                    // make the compiler wait for these loads HERE
@@ -641,13 +643,13 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                     if (kb + 1 < G::NKB && ((TA1 >= T && TA1 <= Tl && !late) || (TB1 >= T && TB1 <= Tl && late))) {
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("" : "+v"(ops_cur.o1a), "+v"(ops_cur.o2a));
-                        te0 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 2] * unscale, ops_cur.o1a, ops_cur.o2a, ops_cur.o3a, stash_base(lin, 2 * kb + 2), vl, isv, tmax);
+                        te0 = epilogue<SW, FL, kTrackE, P24 != 0>(a, prev[2 * kb + 2] * unscale, ops_cur.o1a, ops_cur.o2a, ops_cur.o3a, stash_base(lin, 2 * kb + 2), vl, isv, tmax);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (kb + 1 < G::NKB && ((TA2 >= T && TA2 <= Tl && !late) || (TB2 >= T && TB2 <= Tl && late))) {
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("" : "+v"(ops_cur.o1b), "+v"(ops_cur.o2b));
-                        const f32x4 te1 = epilogue<SW, FL, kTrackE>(a, prev[2 * kb + 3] * unscale, ops_cur.o1b, ops_cur.o2b, ops_cur.o3b, stash_base(lin, 2 * kb + 3), vl, isv, tmax);
+                        const f32x4 te1 = epilogue<SW, FL, kTrackE, P24 != 0>(a, prev[2 * kb + 3] * unscale, ops_cur.o1b, ops_cur.o2b, ops_cur.o3b, stash_base(lin, 2 * kb + 3), vl, isv, tmax);
                         split(te0, te1, nb);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -763,7 +765,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
 // an LDS-DMA round trip: with the chunk stream the pass was bound by DMA latency).  Two barriers per layer, no hand-counted
 // waits; the chunk buffers and `gc` are left alone.
 constexpr int kOctBytes = 8 * 2 * 1024 + 1024 + 8 * 64 * 16;      // B fragments | column maxima (2 x 128 floats) | output-stage partials
-template <int H, int SW, int FL>
+template <int H, int SW, int FL, int P24 = 0>
 __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, char* lds, unsigned& gc, const unsigned oct_off) {
     using G = GeoB<H, 1>;
     static_assert(H == 256 && SW <= SWEEP_ADJ_REV, "fp16x3, plain columns, one k-block per wave");
@@ -789,7 +791,8 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
-    const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);
+    const LaneOff vo((unsigned)(((int64_t)q * a.np + p) * 16), (unsigned)(((int64_t)q * a.np + p) * 16),
+                     P24 ? (unsigned)(((p >> 4) * 64 + lane) * 12) : 0u);
     char* ox = lds + oct_off;
     u32x4* Bx = reinterpret_cast<u32x4*>(ox);                          // [k-block][piece][lane]
     float* cmx = reinterpret_cast<float*>(ox + 8 * NPC * 1024);        // [wave][column]: max |accumulator|
@@ -818,7 +821,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
     auto load_ops = [&](int layer) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            epilogue_loads<SW, FL>(a, stash_base(layer, T0 + u), vo, o1[u], o2[u], o3[u]);
+            epilogue_loads<SW, FL, P24 != 0>(a, stash_base(layer, T0 + u), vo, o1[u], o2[u], o3[u]);
             if constexpr (BS == SWEEP_FWD)
                 bs[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + 3 * G::CHUNKB) + layer * H + 16 * (T0 + u) + 4 * q);
         }
@@ -858,7 +861,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
             f32x4 z = prev[u];
             if constexpr (BS == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[u]);
             else z *= unscale;
-            e[u] = epilogue<SW, FL, kTrackE>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
+            e[u] = epilogue<SW, FL, kTrackE, P24 != 0>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
         }
         if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) lds_max_wave(lds_amax + lin, tk.t); tk.t = 0.f; }
         if constexpr (kTrackE) {
@@ -960,7 +963,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
 
 // (bid, nblk): this workgroup's index among the `nblk` that share the columns of `a` — the whole grid, or one of the two
 // parts of a pair launch (sweep_pair_kernel)
-template <int H, int SW, int FL, int SP = 0>
+template <int H, int SW, int FL, int SP = 0, int P24 = 0>
 __device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     unsigned gc = 0;
@@ -990,11 +993,11 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, 
         if constexpr (kOct) {
             if (g1 - g == 1) {                          // a pass with one group: all eight waves share it
                 const unsigned oct_off = 3 * GeoB<H, SP>::CHUNKB + (base_of(SW) == SWEEP_FWD ? (unsigned)(a.L * H * sizeof(float)) : (unsigned)(kMaxAmaxLayers * sizeof(unsigned)));
-                sweep_tile_oct<H, SW, FL>(a, gbase + g, lds_b, gc, oct_off);
+                sweep_tile_oct<H, SW, FL, P24>(a, gbase + g, lds_b, gc, oct_off);
                 continue;
             }
         }
-        sweep_tile_b<H, SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && bid == 100 && g == g0);
+        sweep_tile_b<H, SW, FL, SP, P24>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_b, gc, (DUDF_SWEEP_DBG & 128) && bid == 100 && g == g0);
     }
     if constexpr (kRow >= 0) {
         __syncthreads();
@@ -1024,16 +1027,21 @@ template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
+// ... and the fp16x3 builds that keep the backward-only stash arrays at 24 bits, tile-major (dudf_internal.h "p24"; training variants)
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_f16p_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 1>(a, blockIdx.x, gridDim.x); }
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16p_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 1>(a, blockIdx.x, gridDim.x); }
 // Pair launch (a batch with Hessian-path points: `loss_s1` with its eigenvector term, the reference's shipped recipe).  A sweep
 // then has two column ranges — the quads (variant SWQ; fp16x3 or, SPQ = 0, bf16x6) and the plain columns (fp16x3, variant SWP) — which used to be
 // two launches of <= 256 persistent workgroups each: at the reference's batch (29 970 points = 312 + 156 tiles of 128 columns)
 // that is 1.2 rounds + 0.6 rounds, each rounded up by the tail of its own launch.  Here ONE grid carries both: the first
 // `nbq` workgroups walk the quads, the rest the plain columns, and the host splits the 256 workgroups so that both parts
 // finish together (launch_pair).  The two bodies are the ones above, unchanged.
-template <int H, int SWQ, int FLQ, int SWP, int FLP, int SPQ>
+template <int H, int SWQ, int FLQ, int SWP, int FLP, int SPQ, int P24 = 0>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_pair_kernel(SweepArgs aq, SweepArgs ap, int nbq) {
-    if ((int)blockIdx.x < nbq) sweep_body_b<H, SWQ, FLQ, SPQ>(aq, blockIdx.x, nbq);
-    else sweep_body_b<H, SWP, FLP, 1>(ap, (int)blockIdx.x - nbq, (int)gridDim.x - nbq);
+    if ((int)blockIdx.x < nbq) sweep_body_b<H, SWQ, FLQ, SPQ, P24>(aq, blockIdx.x, nbq);
+    else sweep_body_b<H, SWP, FLP, 1, P24>(ap, (int)blockIdx.x - nbq, (int)gridDim.x - nbq);
 }
 
 // theta -> bf16x3 images in A-fragment order of W_l (forward sweeps) and W_l^T (reverse sweeps), l = 2..L
@@ -1242,21 +1250,29 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         constexpr size_t smem_fmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + oct;
         constexpr size_t smem_o = w3 + kMaxAmaxLayers * sizeof(unsigned) + oct;   // + the per-layer running maxima
         bool done = true;
+        // 24-bit tile-major stash (SweepArgs::p24, H = 256): the training variants have a build of their own
+#define DUDF_GO_HP(SW, FL, KERNEL, KERNELP, SMEM_MAX, SMEM)                                                 \
+        do {                                                                                                    \
+            bool p_ = false;                                                                                    \
+            if constexpr (H == 256) { if (a.p24) { DUDF_GO_H(SW, FL, KERNELP, SMEM_MAX, SMEM); p_ = true; } }   \
+            if (!p_) { if (a.p24) return DUDF_E_UNSUPPORTED; DUDF_GO_H(SW, FL, KERNEL, SMEM_MAX, SMEM); }       \
+        } while (0)
         if (which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {
-            if (a.store_s && a.store_c) DUDF_GO_H(SWEEP_FWD, 3, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
+            if (a.store_s && a.store_c) DUDF_GO_HP(SWEEP_FWD, 3, DUDF_FWD_F16_KERNEL, sweep_f16p_np_kernel, smem_fmax, smem_f);
             else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
             else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
             else return DUDF_E_BADMODE;
         } else if (which == SWEEP_REV) {
-            if (a.train) DUDF_GO_H(SWEEP_REV, 1, sweep_f16_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_REV, 0, sweep_f16_kernel, smem_o, smem_o);
+            if (a.train) DUDF_GO_HP(SWEEP_REV, 1, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_REV, 0, sweep_f16_kernel, smem_o, smem_o);
         } else if (which == SWEEP_ADJ_FWD) {
-            DUDF_GO_H(SWEEP_ADJ_FWD, 0, sweep_f16_kernel, smem_o, smem_o);
+            DUDF_GO_HP(SWEEP_ADJ_FWD, 0, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o);
         } else if (which == SWEEP_ADJ_REV && (!a.have_e || (a.ebound && ((a.split >> SWEEP_ADJ_FWD) & 1)))) {
-            if (a.have_e) DUDF_GO_H(SWEEP_ADJ_REV, 1, sweep_f16_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_ADJ_REV, 0, sweep_f16_kernel, smem_o, smem_o);
+            if (a.have_e) DUDF_GO_HP(SWEEP_ADJ_REV, 1, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o); else DUDF_GO_HP(SWEEP_ADJ_REV, 0, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o);
         } else {
             done = false;
         }
         if (done) return (int)hipGetLastError();
+        if (a.p24) return DUDF_E_UNSUPPORTED;                  // a 24-bit workspace has no other kernels
     }
     // ... and the Hessian quads' sweeps (bit 5, DUDF_SPLIT_QUADS; the jets stay on bf16x6).  All of a workspace's or none:
     // the forward sweep leaves zbound for the other three, the adjoint forward sweep ebound for the adjoint reverse one.
@@ -1266,13 +1282,14 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         const size_t smem_fq = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         constexpr size_t smem_fqmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         bool done = true;
-        if (which == SWEEP_FWD_H) { if (a.store_s) DUDF_GO_H(SWEEP_FWD_H, 1, sweep_f16_np_kernel, smem_fqmax, smem_fq); else DUDF_GO_H(SWEEP_FWD_H, 0, sweep_f16_np_kernel, smem_fqmax, smem_fq); }
-        else if (which == SWEEP_REV_H) { if (a.train) DUDF_GO_H(SWEEP_REV_H, 1, sweep_f16_np_kernel, smem_q, smem_q); else DUDF_GO_H(SWEEP_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q); }
-        else if (which == SWEEP_ADJ_FWD_H && a.ebound) DUDF_GO_H(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
-        else if (which == SWEEP_ADJ_REV_H && a.ebound) DUDF_GO_H(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q);
+        if (which == SWEEP_FWD_H) { if (a.store_s) DUDF_GO_HP(SWEEP_FWD_H, 1, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_fqmax, smem_fq); else DUDF_GO_H(SWEEP_FWD_H, 0, sweep_f16_np_kernel, smem_fqmax, smem_fq); }
+        else if (which == SWEEP_REV_H) { if (a.train) DUDF_GO_HP(SWEEP_REV_H, 1, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q); else DUDF_GO_H(SWEEP_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q); }
+        else if (which == SWEEP_ADJ_FWD_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
+        else if (which == SWEEP_ADJ_REV_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
         else done = false;
         if (done) return (int)hipGetLastError();
     }
+    if (a.p24 && which != SWEEP_FWD_J) return DUDF_E_UNSUPPORTED;     // (the jets stash nothing)
     if (which == SWEEP_FWD_J && (a.split & 32) && a.L <= kMaxLdsBiasLayers) {      // the third-order jets (curvature query): nothing stashed
         constexpr size_t w3 = 3 * GeoB<H, 1>::CHUNKB;
         const size_t smem_j = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
@@ -1280,6 +1297,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         DUDF_GO_H(SWEEP_FWD_J, 0, sweep_f16_np_kernel, smem_jmax, smem_j);
         return (int)hipGetLastError();
     }
+#undef DUDF_GO_HP
 #undef DUDF_GO_H
     switch (which) {
         case SWEEP_FWD:
@@ -1736,17 +1754,17 @@ constexpr size_t kPairSmemQ = 3 * GeoB<256, 0>::CHUNKB + kMaxAmaxLayers * sizeof
 constexpr size_t kPairSmemP = 3 * GeoB<256, 1>::CHUNKB + kMaxLdsBiasLayers * 256 * sizeof(float) + kOctBytes;     // the plain body's, at most
 constexpr size_t kPairSmemMax = kPairSmemQ > kPairSmemP ? kPairSmemQ : kPairSmemP;
 static_assert(kPairSmemMax <= 160 * 1024, "LDS of a CU");
-template <int SWQ, int FLQ, int SWP, int FLP, int SPQ>
+template <int SWQ, int FLQ, int SWP, int FLP, int SPQ, int P24 = 0>
 int launch_pair_t(const SweepArgs& aq, const SweepArgs& ap, size_t smem, int nbq, int nbp, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP, SPQ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP, SPQ, P24>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kPairSmemMax);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP, SPQ>), dim3(nbq + nbp), dim3(GeoB<256>::NTHR), smem, st, aq, ap, nbq);
+    hipLaunchKernelGGL((sweep_pair_kernel<256, SWQ, FLQ, SWP, FLP, SPQ, P24>), dim3(nbq + nbp), dim3(GeoB<256>::NTHR), smem, st, aq, ap, nbq);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -1785,6 +1803,13 @@ int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq0, const SweepArg
     const bool q16 = (aq.split & 32) && aq.zbound && aq.ebound;       // the quads on fp16x3 as well (their LDS is then the smaller part)
     const size_t sq = q16 ? w3 + (base == SWEEP_FWD ? (size_t)aq.L * 256 * sizeof(float) : 0) + kMaxAmaxLayers * sizeof(unsigned) : kPairSmemQ;
     const size_t smem = sq > sp ? sq : sp;
+    if (ap.p24 != aq.p24 || (ap.p24 && !q16)) return DUDF_E_UNSUPPORTED;   // (the 24-bit stash needs the quads on fp16x3 too: dudf_stash_p24_enabled)
+    if (ap.p24) switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 1>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 1>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 1>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 1>(aq, ap, smem, nbq, nbp, st);
+    }
     if (q16) switch (base) {
         case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1>(aq, ap, smem, nbq, nbp, st);
         case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1>(aq, ap, smem, nbq, nbp, st);

@@ -80,6 +80,44 @@ __device__ __forceinline__ f32x4 dudf_dbg_any() { f32x4 z; asm volatile("" : "=v
 #endif
 #endif
 
+// ---- 24-bit tile-major stash arrays (dudf_internal.h, "p24") -----------------------------------------------------------------
+// four fp32 values -> three dwords: round to nearest at bit 8 (an integer add on the bit pattern: a carry out of the mantissa
+// lands in the exponent, as it should), then the top three bytes of each value, packed by v_perm_b32 (selector bytes 0-3 pick
+// from the SECOND source, 4-7 from the first, 0x0c is the constant 0).  7 vector-ALU instructions per tile and array to write,
+// 4 to read — beside an HBM-bound sweep.
+typedef unsigned dudf_u3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ dudf_u3 p24_pack(const f32x4 v) {
+    const unsigned u0 = __float_as_uint(v[0]) + 0x80u, u1 = __float_as_uint(v[1]) + 0x80u,
+                   u2 = __float_as_uint(v[2]) + 0x80u, u3 = __float_as_uint(v[3]) + 0x80u;
+    dudf_u3 d;
+    d.x = __builtin_amdgcn_perm(u1, u0, 0x05030201u);
+    d.y = __builtin_amdgcn_perm(u2, u1, 0x06050302u);
+    d.z = __builtin_amdgcn_perm(u3, u2, 0x07060503u);
+    return d;
+}
+__device__ __forceinline__ f32x4 p24_unpack(const dudf_u3 d) {
+    return f32x4{__uint_as_float(d.x << 8), __uint_as_float(__builtin_amdgcn_perm(d.y, d.x, 0x0504030cu)),
+                 __uint_as_float(__builtin_amdgcn_perm(d.z, d.y, 0x0403020cu)), __uint_as_float(d.z & 0xffffff00u)};
+}
+// `ub` is the same wave-uniform float offset as for the fp32 arrays ((layer * H + 16 T) * np): the tile-major byte offset of
+// (layer, T) is exactly 3 * ub; `vt` = the lane's ((p / 16) * 64 + lane) * 12
+#define DUDF_AT24(arr, ub, vt) reinterpret_cast<dudf_u3*>(reinterpret_cast<char*>(arr) + 3 * (ub) + (vt))
+#define DUDF_CAT24(arr, ub, vt) reinterpret_cast<const dudf_u3*>(reinterpret_cast<const char*>(arr) + 3 * (ub) + (vt))
+#if DUDF_SWEEP_DBG & 1
+#define DUDF_ST24(arr, ub, vt, val) asm volatile("" :: "v"(p24_pack((f32x4)(val))))
+#else
+#define DUDF_ST24(arr, ub, vt, val) __builtin_nontemporal_store(p24_pack((f32x4)(val)), DUDF_AT24(arr, ub, vt))
+#endif
+#if DUDF_SWEEP_DBG & 2
+__device__ __forceinline__ dudf_u3 dudf_dbg_any3() { dudf_u3 z; asm volatile("" : "=v"(z)); return z; }
+#define DUDF_LD24(arr, ub, vt) p24_unpack(dudf_dbg_any3())
+#else
+#define DUDF_LD24(arr, ub, vt) p24_unpack(__builtin_nontemporal_load(DUDF_CAT24(arr, ub, vt)))
+#endif
+// a backward-only array in the format of this build: P (compile-time) = 24-bit tile-major, else fp32 rows
+#define DUDF_STB(P, arr, ub, lo, val) do { if constexpr (P) DUDF_ST24(arr, ub, (lo).t, val); else DUDF_ST(arr, ub, (lo).v, val); } while (0)
+#define DUDF_LDB(P, arr, ub, lo) ((P) ? DUDF_LD24(arr, ub, (lo).t) : DUDF_LD(arr, ub, (lo).v))
+
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
 // (the empty asm pins the DPP source to an ARCHITECTURAL vector register: in the 512-register kernels of the 512-wide
 //  layers hipcc 7.2 keeps values in accumulation registers and then emits DPP moves that read them, which the assembler
@@ -171,13 +209,15 @@ __device__ __forceinline__ void dudf_track(float& tmax, const f32x4 v) {
 // is the same number in all four channels of a quad (it is the VALUE channel's), so C keeps ONE copy per quad — at column
 // (p >> 2) of the quad region, written and read by all four lanes (same bits, same granule: one 16-byte access serves four lanes) —
 // instead of four: 3 of the quad sweeps' 16 stash units per column gone.
+// `t`: the lane's byte offset inside a (layer, tile) block of a 24-bit tile-major array (0 where the build has none).
 struct LaneOff {
-    unsigned v, c;
-    __device__ __forceinline__ LaneOff(unsigned x) : v(x), c(x) {}
-    __device__ __forceinline__ LaneOff(unsigned x, unsigned y) : v(x), c(y) {}
+    unsigned v, c, t;
+    __device__ __forceinline__ LaneOff(unsigned x) : v(x), c(x), t(0) {}
+    __device__ __forceinline__ LaneOff(unsigned x, unsigned y) : v(x), c(y), t(0) {}
+    __device__ __forceinline__ LaneOff(unsigned x, unsigned y, unsigned z) : v(x), c(y), t(z) {}
 };
 
-template <int SW, int FL, bool TE = false>
+template <int SW, int FL, bool TE = false, bool P24 = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
                                           const LaneOff lo, bool isv, TailTrack& tk) {
     const unsigned vo = lo.v;
@@ -190,24 +230,24 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
             s[t] = sv.x; s[t + 1] = sv.y; c[t] = cv.x; c[t + 1] = cv.y;
         }
-        if constexpr (FL & 1) DUDF_ST(a.S, ub, vo, s);
+        if constexpr (FL & 1) DUDF_STB(P24, a.S, ub, lo, s);
         if constexpr (FL & 2) DUDF_ST(a.C, ub, vo, c);
         out = s;
     } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
         out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
         if constexpr (FL & 1) {
-            DUDF_ST(a.Q, ub, vo, out);
-            DUDF_ST(a.R, ub, vo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
+            DUDF_STB(P24, a.Q, ub, lo, out);
+            DUDF_STB(P24, a.R, ub, lo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
-        DUDF_ST(a.A, ub, vo, out);
+        DUDF_STB(P24, a.A, ub, lo, out);
         const f32x4 ev = o2 * acc;                   // e_l = r_l Q_l
-        DUDF_ST(a.E, ub, vo, ev);
+        DUDF_STB(P24, a.E, ub, lo, ev);
         if constexpr (TE) dudf_track(tk.e, ev);      // (per column: what bounds zbar_l in the fp16x3 adjoint reverse sweep)
     } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
-        DUDF_ST(a.Z, ub, vo, out);
+        DUDF_STB(P24, a.Z, ub, lo, out);
     } else if constexpr (SW == SWEEP_FWD_H) {
         f32x4 c, zs;
 #pragma unroll
@@ -220,7 +260,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         DUDF_ST(a.C, ub, lo.c, c);   // one copy per quad (LaneOff): the four lanes hold the same bits and write the same granule — no branch
         DUDF_ST(a.ZS, ub, vo, zs);
-        if constexpr (FL & 1) DUDF_ST(a.S, ub, vo, out);
+        if constexpr (FL & 1) DUDF_STB(P24, a.S, ub, lo, out);
     } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -228,8 +268,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = isv ? a.w0 * o1[t] * acc[t] : a.w0 * (o1[t] * acc[t] - a.w0 * sv * o2[t] * a0);
         }
         if constexpr (FL & 1) {
-            DUDF_ST(a.Q, ub, vo, out);
-            DUDF_ST(a.R, ub, vo, acc);
+            DUDF_STB(P24, a.Q, ub, lo, out);
+            DUDF_STB(P24, a.R, ub, lo, acc);
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {    // o1 = c, o2 = s|zdot^k, o3 = a|adot^k
         f32x4 e;
@@ -246,8 +286,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = a.w0 * (o1[t] * acc[t] + (isv ? s1 : 0.f));
             e[t] = isv ? a.w0 * (o1[t] * sbar - sv * cbar) : -a.w0 * sv * chat;
         }
-        DUDF_ST(a.A, ub, vo, out);
-        DUDF_ST(a.E, ub, vo, e);
+        DUDF_STB(P24, a.A, ub, lo, out);
+        DUDF_STB(P24, a.E, ub, lo, e);
         if constexpr (TE) dudf_track(tk.e, e);
     } else if constexpr (SW == SWEEP_FWD_J) {
         const int lane = threadIdx.x & 63, l0 = lane & 48;
@@ -274,37 +314,37 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             const float st = quad_sum(isv ? 0.f : o2[t] * acc[t]);
             out[t] = o3[t] + a.w0 * o1[t] * acc[t] - (isv ? a.w0 * a.w0 * sv * st : 0.f);
         }
-        DUDF_ST(a.Z, ub, vo, out);
+        DUDF_STB(P24, a.Z, ub, lo, out);
     }
     if constexpr (amax_row<SW, FL>() >= 0) dudf_track(tk.t, out);
     return out;
 }
 
-template <int SW, int FL>
+template <int SW, int FL, bool P24 = false>
 __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, const LaneOff lo, f32x4& o1, f32x4& o2,
                                                f32x4& o3) {
     o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
     const unsigned vo = lo.v;
     if constexpr (SW == SWEEP_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = DUDF_LD(a.S, ub, vo);
+        if constexpr (FL & 1) o2 = DUDF_LDB(P24, a.S, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
         o1 = DUDF_LD(a.C, ub, vo);
-        o2 = DUDF_LD(a.R, ub, vo);
+        o2 = DUDF_LDB(P24, a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = DUDF_LD(a.E, ub, vo);            // no df/dx terms (loss_s2): e_l == 0
+        if constexpr (FL & 1) o2 = DUDF_LDB(P24, a.E, ub, lo);      // no df/dx terms (loss_s2): e_l == 0
     } else if constexpr (SW == SWEEP_REV_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
-        o3 = DUDF_LD(a.R, ub, vo);
+        o3 = DUDF_LDB(P24, a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
-        o3 = DUDF_LD(a.E, ub, vo);
+        o3 = DUDF_LDB(P24, a.E, ub, lo);
     }
 }
 

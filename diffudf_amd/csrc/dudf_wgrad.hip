@@ -46,6 +46,7 @@ struct WgradArgs {
     int remap_nsplit;                   // > 0: 1-D grid, the output tiles of one (layer, column split) share an XCD (see the body)
     unsigned long long* clk;            // profiling: (shader clock, 100 MHz reference) ticks of workgroup (0,0,0), or nullptr
     const unsigned* amax;               // [4][L] bit patterns of max |q_l|, |A_l|, |zbar_l| over all columns (fp16x3 kernel)
+    int p24;                            // the operands are 24-bit tile-major arrays (DudfLayout::p24)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -85,10 +86,11 @@ __device__ __forceinline__ void wgrad_hidden_body(const WgradArgs& a) {
     }
 
     // pair 0: X = q_l (layer index j+1), Y = A_{l-1} (index j);  pair 1: X = zbar_l, Y = s_{l-1}
-    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer + xrow;
-    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer + xrow;
-    const float* Y0 = a.A + (int64_t)j * a.stash_layer + yrow;
-    const float* Y1 = a.S + (int64_t)j * a.stash_layer + yrow;
+    const int64_t lstride = a.stash_layer;
+    const float* X0 = a.Q + (int64_t)(j + 1) * lstride + xrow;
+    const float* X1 = a.Z + (int64_t)(j + 1) * lstride + xrow;
+    const float* Y0 = a.A + (int64_t)j * lstride + yrow;
+    const float* Y1 = a.S + (int64_t)j * lstride + yrow;
 
     f32x4 rx[NLD], ry[NLD];
     auto issue = [&](int pair, int step) {
@@ -281,10 +283,11 @@ __device__ __forceinline__ void wgrad_hidden_bf16_body(const WgradArgs& a) {
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
         bsum[m] = 0.f;
     }
-    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer + xrow;
-    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer + xrow;
-    const float* Y0 = a.A + (int64_t)j * a.stash_layer + yrow;
-    const float* Y1 = a.S + (int64_t)j * a.stash_layer + yrow;
+    const int64_t lstride = a.stash_layer;
+    const float* X0 = a.Q + (int64_t)(j + 1) * lstride + xrow;
+    const float* X1 = a.Z + (int64_t)(j + 1) * lstride + xrow;
+    const float* Y0 = a.A + (int64_t)j * lstride + yrow;
+    const float* Y1 = a.S + (int64_t)j * lstride + yrow;
 
     const int npair = a.have_g ? 2 : 1;
     const int nit = npair * (s1 - s0);
@@ -445,18 +448,29 @@ __device__ __forceinline__ int dudf_exp_above(unsigned bits) {     // e with |v|
 }
 __device__ __forceinline__ float dudf_pow2(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
-template <int H, int VAR, int SP = 0>
+// P24 = 1: the operands arrive as 24-bit tile-major stash arrays (dudf_internal.h "p24": [layer][feature tile][16-column group]
+// [64 lanes][3 dwords]).  A 16-column stage of an operand is then 16 contiguous 768-byte blocks, one per feature tile: a wave
+// loads a block with ONE dwordx3 instruction (six full lines), lane (q, li) holding features 16 T + 4 q .. + 3 of column li.
+// A lane therefore has many features of ONE column — the transpose of what the MFMA wants (one feature, 8 columns) — so the
+// LDS image is [column k][feature] (rows of 576 bytes: 256 fp16 + 64, four consecutive rows start 16 banks apart; the
+// 8-byte unit index of a row XORed in its low three bits with (k >> 1) & 7: a 16-lane ds_write_b64 service group covers
+// the 32 write banks once) and the fragments come out of it through ds_read_b64_tr_b16, gfx950's transposing LDS read: a
+// 16-lane group reads 4 rows (columns k) x 16 features and every lane receives its feature's four k — two of them per
+// fragment (tools/micro/tr_image.hip checks image, swizzle and fragment maps against a host GEMM).
+template <int H, int VAR, int SP = 0, int P24 = 0>
 __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     using W = WG<H>;
     static_assert(H == 256, "256 x 256 output tiles");
+    static_assert(P24 == 0 || (SP != 0 && (VAR & 8) != 0), "24-bit operands: the fp16x3, flag-synchronised build");
     constexpr int NPC = SP ? 2 : 3;                         // pieces per operand
     constexpr int NW_ = W::WO * W::WI;
     constexpr int FQ = H / 4;
     constexpr int HALFB = 32 * 16 + 16;                     // 32 features x 8 columns of a block, +16: the second column half
     constexpr int BLKB = 2 * HALFB;                         //   must not sit 512 B = 0 banks after the first (ds_write_b64)
-    constexpr int PIECEB = (H / 32) * BLKB;                 // 8.25 KiB
-    constexpr int OPERB = NPC * PIECEB;                     // 24 KiB (16.5)
-    constexpr int BUFB = 2 * OPERB;                         // 48 KiB (33)
+    constexpr int ROWB = 576;                               // P24: one column's 256 fp16 + 64 bytes
+    constexpr int PIECEB = P24 ? 16 * ROWB : (H / 32) * BLKB;   // 8.25 KiB (P24: 9)
+    constexpr int OPERB = NPC * PIECEB;                     // 24 KiB (16.5; P24: 18)
+    constexpr int BUFB = 2 * OPERB;                         // 48 KiB (33; P24: 36)
     extern __shared__ __attribute__((aligned(16))) char ldsb[];     // [2 buffers][X | Y][h | m | l][feature][16 columns]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -490,10 +504,12 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         for (int n = 0; n < W::NTL; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-    const float* X0 = a.Q + (int64_t)(j + 1) * a.stash_layer + xrow;
-    const float* X1 = a.Z + (int64_t)(j + 1) * a.stash_layer + xrow;
-    const float* Y0 = a.A + (int64_t)j * a.stash_layer + yrow;
-    const float* Y1 = a.S + (int64_t)j * a.stash_layer + yrow;
+    // (P24: a layer of a 24-bit array is 3/4 of stash_layer floats; H == Hs, so xrow == yrow == 0)
+    const int64_t lstride = P24 ? a.stash_layer / 4 * 3 : a.stash_layer;
+    const float* X0 = a.Q + (int64_t)(j + 1) * lstride + xrow;
+    const float* X1 = a.Z + (int64_t)(j + 1) * lstride + xrow;
+    const float* Y0 = a.A + (int64_t)j * lstride + yrow;
+    const float* Y1 = a.S + (int64_t)j * lstride + yrow;
 
     const int npair = a.have_g ? 2 : 1;
     const int nit = npair * (s1 - s0);
@@ -512,9 +528,12 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     const int64_t p_goff = ((int64_t)p_fq * a.np + p_cg) * 4;             // floats, + col0 * 4 per stage
     // image of one piece: [32-feature block][column half][feature in block][8 columns] = the fragment order of the MFMA
     const int p_loff = p_oper * OPERB + (p_fq >> 3) * BLKB + (p_cg >> 1) * HALFB + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
-    struct RawSet { f32x4 g0, g1, g2, g3; };                              // granule j: 4 features of column 4*cg + j
+    typedef unsigned u3_t __attribute__((ext_vector_type(3)));
+    typedef typename std::conditional<P24 != 0, u3_t, f32x4>::type raw_t;      // P24: a granule is 3 dwords (four 24-bit values)
+    struct RawSet { raw_t g0, g1, g2, g3; };                              // granule j: 4 features of column 4*cg + j (P24: of tile 4 pw + j, column li)
     RawSet R0, R1, R2;                                                    // stage s travels in set s % 3, three stages ahead
     f32x4 bacc = {0.f, 0.f, 0.f, 0.f};                                    // bias gradient partial sums (X operand, zbar pair)
+    f32x4 bacc1 = bacc, bacc2 = bacc, bacc3 = bacc;                       // P24: one quad of features per tile
     const float* P0 = p_oper ? Y0 : X0;                                   // this wave's operand for the (q, A) / (zbar, s) pair
     const float* P1 = p_oper ? Y1 : X1;
     // fp16x3: this wave's operand scale for each pair, and the common product scale 2^P of the layer
@@ -538,23 +557,49 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     // arithmetic in vector registers (the launcher keeps FQ * np * 16 below 2^32)
     const unsigned p_voff = (unsigned)(p_goff * 4);
     const float bm_plain = (p_oper == 0 && i_off == 0) ? 1.f : 0.f;     // this lane's granules count towards the bias gradient ...
-    const float bm_quad = (p_cg == 0) ? bm_plain : 0.f;                  // ... on a Hessian-quad stage
+    const float bm_quad = ((P24 ? (lane & 3) : p_cg) == 0) ? bm_plain : 0.f;   // ... on a Hessian-quad stage (the value channel: column % 4 == 0)
+    // P24 producer role: wave pw (0..3 of its operand) stages feature tiles 4 pw .. 4 pw + 3; lane = (q, li) as in the sweeps
+    const int pw = wave & (NW_ / 2 - 1), p_q = lane >> 4, p_li = lane & 15;
+    const int64_t ngrp = a.np >> 4;                                       // 16-column groups per row of tiles
+    const unsigned t_voff0 = (unsigned)(lane * 12 + (int64_t)(4 * pw) * ngrp * 768);   // (dudf_make_layout keeps H * np * 3 below 2^32)
+    const unsigned t_vstep = (unsigned)(ngrp * 768);
+    // image write offsets of this lane (row li, unit 16 pw + 4 t + q with its low three bits swizzled): tiles with even / odd t
+    const int p_sw = (p_li >> 1) & 7;
+    const int t_w0 = p_oper * OPERB + p_li * ROWB + 128 * pw + 8 * (p_q ^ p_sw), t_w1 = p_oper * OPERB + p_li * ROWB + 128 * pw + 8 * ((4 + p_q) ^ p_sw);
     auto load_raw = [&](int it, RawSet& r) {
+        if constexpr (P24 != 0) {
+            const uint64_t g0 = (uint64_t)(size_t)(reinterpret_cast<const char*>(pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * 768);
+            const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
+            const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
+            asm volatile("global_load_dwordx3 %0, %4, %8" DUDF_WG_NT "\n\tglobal_load_dwordx3 %1, %5, %8" DUDF_WG_NT "\n\t"
+                         "global_load_dwordx3 %2, %6, %8" DUDF_WG_NT "\n\tglobal_load_dwordx3 %3, %7, %8" DUDF_WG_NT
+                         : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3)
+                         : "v"(t_voff0), "v"(t_voff0 + t_vstep), "v"(t_voff0 + 2 * t_vstep), "v"(t_voff0 + 3 * t_vstep), "s"(sbase) : "memory");
+        } else {
         const uint64_t g0 = (uint64_t)(size_t)((pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * KB * 4);
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
         const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
         asm volatile("global_load_dwordx4 %0, %4, %5" DUDF_WG_NT "\n\tglobal_load_dwordx4 %1, %4, %5 offset:64" DUDF_WG_NT "\n\t"
                      "global_load_dwordx4 %2, %4, %5 offset:128" DUDF_WG_NT "\n\tglobal_load_dwordx4 %3, %4, %5 offset:192" DUDF_WG_NT
                      : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3) : "v"(p_voff), "s"(sbase) : "memory");
+        }
     };
     // outside the steady-state loop (prologue, last stages: conditional loads) the loads are ordinary ones: a conditional
     // asm load makes hipcc merge "loaded" and "not loaded" values with register copies — of registers still in flight
     auto load_raw_plain = [&](int it, RawSet& r) {
+        if constexpr (P24 != 0) {
+            const char* src = reinterpret_cast<const char*>(pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * 768 + t_voff0;
+            r.g0 = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(src));
+            r.g1 = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(src + t_vstep));
+            r.g2 = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(src + 2 * (size_t)t_vstep));
+            r.g3 = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(src + 3 * (size_t)t_vstep));
+        } else {
         const float* src = (pair_of(it) ? P1 : P0) + p_goff + (int64_t)step_of(it) * KB * 4;
         r.g0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
         r.g1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 4);
         r.g2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 8);
         r.g3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + 12);
+        }
     };
     auto wait_raw = [&](RawSet& r, auto younger) {       // this set has landed; `younger` loads issued after it stay in flight
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.g0), "+v"(r.g1), "+v"(r.g2), "+v"(r.g3) : "n"(decltype(younger)::value));
@@ -595,6 +640,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                      : "s"(flag0), "s"(need_w), "s"(need_r), "s"(need_h03), "s"(need_h47) : "memory", "vcc", "scc");
     };
     auto split_slice = [&](int it, const RawSet& r, int f, int bsel) {    // feature f of the lane's quad -> piece image buffer bsel
+      if constexpr (P24 == 0) {
         char* dst = ldsb + bsel * BUFB + p_loff + 16 * f;
         if (f == 0) {
             // Hessian quads: only columns % 4 == 0 (the value channel) carry the bias — all four granules of the lanes
@@ -631,20 +677,73 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
         *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(dst + PIECEB) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(dst + 2 * PIECEB) = u32x2{l0, l1};
+      }
+    };
+    // P24: tile t of this lane's four (features 16 (4 pw + t) + 4 q .. + 3 of column li): unpack, bias sums, fp16 hi / lo, two
+    // 8-byte writes into row li of the [column][feature] image
+    auto split_tile = [&](int it, const raw_t& g, f32x4& bsum, int t, int bsel, const float bmask, const float scl) {
+        if constexpr (P24 != 0) {
+            const unsigned d0 = g[0], d1 = g[1], d2 = g[2];
+            const f32x4 v = {__uint_as_float(d0 << 8), __uint_as_float(__builtin_amdgcn_perm(d1, d0, 0x0504030cu)),
+                             __uint_as_float(__builtin_amdgcn_perm(d2, d1, 0x0403020cu)), __uint_as_float(d2 & 0xffffff00u)};
+            bsum += bmask * v;
+            const f32x2 v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
+            // hi = fp16(v 2^k) in ONE instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: fp32 sources, fp16 result into one
+            // half of the destination; the product with a power of two is exact, so this is the rounding of multiply + convert)
+            f16x2 h0, h1;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v0.x), "s"(scl));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v0.y), "s"(scl));
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v1.x), "s"(scl));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v1.y), "s"(scl));
+            f32x2 r0, r1;
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0.x) : "v"(v0.x), "s"(scl), "v"(h0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r0.y) : "v"(v0.y), "s"(scl), "v"(h0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r1.x) : "v"(v1.x), "s"(scl), "v"(h1));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1.y) : "v"(v1.y), "s"(scl), "v"(h1));
+            const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            char* dst = ldsb + bsel * BUFB + ((t & 1) ? t_w1 : t_w0) + 64 * (t >> 1);
+            *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            *reinterpret_cast<u32x2*>(dst + PIECEB) = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+        }
     };
     auto split_store = [&](int it, const RawSet& r, int bsel) {           // raw (stage it) -> piece image buffer bsel
+        if constexpr (P24 != 0) {
+            // once per stage: which of this lane's values count towards the bias gradient (zbar pair; on a Hessian-quad stage
+            // only the value channel, column % 4 == 0), and this operand's power of two
+            const float hs = ((int64_t)step_of(it) * KB < a.ncol_h) ? 1.f : 0.f;
+            const float pf = pair_of(it) == 1 ? 1.f : 0.f;
+            const float bmask = pf * (bm_plain + hs * (bm_quad - bm_plain));
+            const float scl = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pair_of(it) ? sc1 : sc0)));
+            split_tile(it, r.g0, bacc, 0, bsel, bmask, scl); split_tile(it, r.g1, bacc1, 1, bsel, bmask, scl);
+            split_tile(it, r.g2, bacc2, 2, bsel, bmask, scl); split_tile(it, r.g3, bacc3, 3, bsel, bmask, scl);
+        } else {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) split_slice(it, r, f, bsel);
+            for (int f = 0; f < 4; ++f) split_slice(it, r, f, bsel);
+        }
     };
     // consumer role: fragment (32-feature block b, piece p) of an operand = 1 KiB, lane-linear
     const int c_lane = (lane >> 5) * HALFB + (lane & 31) * 16;
+    // P24: this lane's two transposed reads of a fragment — rows k = 8 (lane >> 5) + ((lane & 15) >> 2) and k + 4, unit
+    // 8 b + 4 ((lane >> 4) & 1) + (lane & 3) of block b, low three bits swizzled with the row's (k >> 1) & 7
+    const int c_k = 8 * (lane >> 5) + ((lane & 15) >> 2), c_u = 4 * ((lane >> 4) & 1) + (lane & 3);
+    const int c_t0 = c_k * ROWB + 8 * (c_u ^ ((c_k >> 1) & 7)), c_t1 = (c_k + 4) * ROWB + 8 * (c_u ^ (((c_k + 4) >> 1) & 7));
+    auto frag_tr = [&](const char* base) -> u32x4 {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + c_t0)));
+        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + c_t1)));
+        return u32x4{lo.x, lo.y, hi.x, hi.y};
+    };
     auto fragA = [&](const char* buf, int m, int pc) -> u32x4 {
         if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { u32x4 z; asm volatile("" : "=v"(z)); return z; }     // timing only: no LDS read
-        return *reinterpret_cast<const u32x4*>(buf + pc * PIECEB + (wo * W::MT + m) * BLKB + c_lane);
+        if constexpr (P24 != 0) return frag_tr(buf + pc * PIECEB + (wo * W::MT + m) * 64);
+        else return *reinterpret_cast<const u32x4*>(buf + pc * PIECEB + (wo * W::MT + m) * BLKB + c_lane);
     };
     auto fragB = [&](const char* buf, int n, int pc) -> u32x4 {
         if constexpr ((DUDF_WGRAD_DBG & 16) != 0) { u32x4 z; asm volatile("" : "=v"(z)); return z; }
-        return *reinterpret_cast<const u32x4*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
+        if constexpr (P24 != 0) return frag_tr(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * 64);
+        else return *reinterpret_cast<const u32x4*>(buf + OPERB + pc * PIECEB + (wi * W::NTL + n) * BLKB + c_lane);
     };
 
     if constexpr (CS) {
@@ -787,9 +886,9 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
             constexpr int BW = (BI + 2) % 3;
             if (HOT || it + 2 < nit) poll(0u, (unsigned)it, 0u, 0u);                             // image it - 1 read by everybody: its buffer is free
             if constexpr (HOT) {
-                wait_raw(r, std::integral_constant<int, 8>{});
-                split_store(it + 2, r, BW);
-                load_raw(it + 5, r);
+                if constexpr (!(DBG & 1)) wait_raw(r, std::integral_constant<int, 8>{});         // (DBG: timing experiments, wrong results)
+                if constexpr (!(DBG & 8)) split_store(it + 2, r, BW);
+                if constexpr (!(DBG & 1)) load_raw(it + 5, r);
                 publish(flag0 + 4u * (unsigned)wave, (unsigned)it + 3u);                         // images 0 .. it + 2 written
             } else if (it + 2 < nit) {
                 split_store(it + 2, r, BW);
@@ -851,12 +950,24 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
                 }
             }
         if (p_oper == 0 && i_off == 0) {                          // bias gradient: sum the four column groups of a quad first
+            if constexpr (P24 != 0) {                             // ... P24: the 16 columns (lanes li) of features 16 (4 pw + t) + 4 q + e
+                auto red = [&](float v, int f) {
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    if (p_li == 0) atomicAdd(dB + f, v);
+                };
+                const f32x4 bs[4] = {bacc, bacc1, bacc2, bacc3};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red(bs[t][e], 16 * (4 * pw + t) + 4 * p_q + e);
+            } else {
             auto red = [&](float v, int f) {
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 if (p_cg == 0) atomicAdd(dB + 4 * p_fq + f, v);
             };
             red(bacc.x, 0); red(bacc.y, 1); red(bacc.z, 2); red(bacc.w, 3);
+            }
         }
     }
     if (clk_on && tid == 0) {
@@ -874,6 +985,11 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
 template <int H, int VAR>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_f16p_kernel(WgradArgs a) {
     wgrad_hidden_bf16p_body<H, VAR, 1>(a);
+}
+// ... reading 24-bit tile-major operands (dudf_internal.h "p24")
+template <int H, int VAR>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_f16p24_kernel(WgradArgs a) {
+    wgrad_hidden_bf16p_body<H, VAR, 1, 1>(a);
 }
 
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
@@ -954,6 +1070,69 @@ __device__ __forceinline__ void wgrad_small_body(const WgradSmallArgs& a) {
 }
 __global__ __launch_bounds__(256) DUDF_NO_PK void wgrad_small_kernel(WgradSmallArgs a) { wgrad_small_body(a); }
 
+// The same reduction over 24-bit tile-major arrays (dudf_internal.h "p24"): grid.x = column ranges, grid.y = feature tiles; a
+// wave walks 16-column groups, lane = (q, li) as in the sweeps: ONE dwordx3 per array and group (768 contiguous bytes per wave).
+__device__ __forceinline__ f32x4 small_unpack24(const unsigned* g) {
+    typedef unsigned u3_t __attribute__((ext_vector_type(3)));
+    const u3_t d = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(g));
+    const unsigned d0 = d.x, d1 = d.y, d2 = d.z;
+    return f32x4{__uint_as_float(d0 << 8), __uint_as_float(__builtin_amdgcn_perm(d1, d0, 0x0504030cu)),
+                 __uint_as_float(__builtin_amdgcn_perm(d2, d1, 0x0403020cu)), __uint_as_float(d2 & 0xffffff00u)};
+}
+__global__ __launch_bounds__(256) DUDF_NO_PK void wgrad_small_p24_kernel(WgradSmallArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, li = lane & 15, T = blockIdx.y;
+    const int64_t ng = a.np >> 4;
+    const int64_t g0 = (int64_t)blockIdx.x * (a.pts_per_block >> 4);
+    const int64_t gend = (a.ncols + 15) >> 4;
+    const int64_t g1 = g0 + (a.pts_per_block >> 4) < gend ? g0 + (a.pts_per_block >> 4) : gend;
+    const int64_t lbytes = a.stash_layer * 3;                            // bytes per layer of a 24-bit array
+    auto tile = [&](const float* arr, int layer) { return reinterpret_cast<const char*>(arr) + (int64_t)layer * lbytes + (int64_t)T * ng * 768 + lane * 12; };
+    const char* Q0 = tile(a.Q, 0); const char* Z0 = tile(a.Z, 0);
+    const char* AL = tile(a.A, a.L - 1); const char* SL = tile(a.S, a.L - 1);
+    float w1[4][4], wo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = w1[c][3] = 0.f; }
+    float sy = 0.f;
+#pragma unroll 4
+    for (int64_t g = g0 + wave; g < g1; g += 4) {
+        const int64_t p = g * 16 + li;
+        const f32x4 z = small_unpack24(reinterpret_cast<const unsigned*>(Z0 + g * 768));
+        const f32x4 sl = small_unpack24(reinterpret_cast<const unsigned*>(SL + g * 768));
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x4 + p * 4);
+        const float yb = a.ybar[p];
+        f32x4 qv = {0, 0, 0, 0}, al = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
+        if (a.have_g) {
+            qv = small_unpack24(reinterpret_cast<const unsigned*>(Q0 + g * 768));
+            al = small_unpack24(reinterpret_cast<const unsigned*>(AL + g * 768));
+            gb = *reinterpret_cast<const f32x4*>(a.gbar + p * 4);
+        }
+        sy += yb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w1[c][d] += qv[c] * gb[d] + z[c] * xv[d];
+            wo[c] += al[c] * xv[3] + yb * sl[c];
+        }
+    }
+    auto sum16 = [](float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int f = 16 * T + 4 * q + c;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float v = sum16(w1[c][d]);
+            if (li == 0) atomicAdd(d < 3 ? a.dtheta + f * 3 + d : a.dtheta + 3 * a.H + f, v);
+        }
+        const float vo = sum16(wo[c]);
+        if (li == 0) atomicAdd(a.dtheta + a.off_wo + f, vo);
+    }
+    if (T == 0 && q == 0) {                                              // db_out = sum ybar
+        const float v = sum16(sy);
+        if (li == 0) atomicAdd(a.dtheta + a.off_bo, v);
+    }
+}
+
 template <int H>
 int launch_hidden(const WgradArgs& a, hipStream_t st) {
     using W = WG<H>;
@@ -980,6 +1159,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
     // DUDF_WGRAD=f32 selects the f32-input MFMA kernel (A/B testing); default: bf16x6 at fp32 accuracy
     static const bool use_f32 = [] { const char* e = getenv("DUDF_WGRAD"); return e && e[0] == 'f'; }();
     dudf_note_products(PROF_WGRAD_HIDDEN, use_f32 ? 1 : 6);         // (the fp16x3 branch below overrides)
+    if (a.p24 && (use_f32 || H != 256)) return DUDF_E_UNSUPPORTED;   // 24-bit operands: only the cooperative-split fp16x3 kernel reads them
     if (use_f32) {
         hipLaunchKernelGGL((wgrad_hidden_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem, st, a);
     } else {
@@ -993,6 +1173,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
         // DUDF_WGRAD=bf16w keeps the per-wave split kernel for the 256-wide tiles (A/B testing)
         static const bool per_wave = [] { const char* e = getenv("DUDF_WGRAD"); return e && strncmp(e, "bf16w", 5) == 0; }();
         if constexpr (H == 256) {
+            if (a.p24 && per_wave) return DUDF_E_UNSUPPORTED;
             if (!per_wave) {
                 static bool attr3 = false;
                 const size_t smem_p = 2 * 2 * 3 * (size_t)(H / 32) * 2 * (32 * 16 + 16);   // 2 buffers x (X | Y) x 3 pieces x blocks
@@ -1005,6 +1186,20 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                 // MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe).  The plain producer-lane
                 // order and the static-priority variants (round-2 experiments, measured no faster) are no longer built.
                 static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 9; }();
+                if (a.p24) {                                                      // 24-bit tile-major operands: their own build
+                    if (!(dudf_split_fp16() && a.amax && a.L <= 64 && var == 9 && ntz == 1)) return DUDF_E_UNSUPPORTED;
+                    dudf_note_products(PROF_WGRAD_HIDDEN, 3);
+                    static bool attr5 = false;
+                    const size_t smem_t = 3 * (size_t)(2 * 2 * 16 * 576) + 512;    // three buffers x (X | Y) x 2 pieces x 16 rows of 576 B + the flags
+                    if (!attr5) {
+                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_f16p24_kernel<H, 9>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t);
+                        if (e != hipSuccess) return (int)e;
+                        attr5 = true;
+                    }
+                    hipLaunchKernelGGL((wgrad_hidden_f16p24_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t, st, a);
+                    return (int)hipGetLastError();
+                }
                 if (dudf_split_fp16() && a.amax && a.L <= 64 && var == 9) {       // fp16x3 (DUDF_SPLIT=bf16 keeps bf16x6)
                     dudf_note_products(PROF_WGRAD_HIDDEN, 3);
                     static bool attr4 = false;
@@ -1069,6 +1264,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.amax = reinterpret_cast<const unsigned*>(ws + lo.ws_amax);
     a.clk = dudf_prof_clk(PROF_WGRAD_HIDDEN);
     a.remap_nsplit = 0;
+    a.p24 = lo.p24;
     const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
     a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;
@@ -1097,6 +1293,11 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     static const int gy_env = [] { const char* e = getenv("DUDF_SMALL_GY"); return e ? atoi(e) : 0; }();   // A/B testing
     const int fqn = lo.H / 4;                                              // feature quads; a block's 4 waves take one each per round:
     const int gy = gy_env > 0 ? gy_env : (fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1));   // up to 16 groups -> more loads in flight per CU
+    if (lo.p24) {                                   // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
+        s.pts_per_block = (s.pts_per_block + 15) / 16 * 16;
+        hipLaunchKernelGGL(wgrad_small_p24_kernel, dim3((unsigned)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block), lo.H / 16), dim3(256), 0, st, s);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid, gy), dim3(256), 0, st, s);
     return (int)hipGetLastError();
 }

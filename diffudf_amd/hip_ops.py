@@ -43,6 +43,11 @@ def sweeps_on_bf16(hidden, layers, w0=30.0):
     return bool(_lib.load().dudf_sweeps_bf16x6(ctypes.byref(cfg)))
 
 
+def stash_mode(cfg):
+    """0: the training stash is all fp32; 1: its backward-only arrays hold 24-bit values (dudf_stash_mode, include/dudf_hip.h)."""
+    return int(_lib.load().dudf_stash_mode(ctypes.byref(cfg)))
+
+
 def theta_count(cfg):
     n = _lib.load().dudf_theta_count(ctypes.byref(cfg))
     if n < 0:

@@ -213,9 +213,18 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
 
 /* Host-only diagnostic (no GPU work): where the per-column arrays of a training workspace sit.  out (host, 10 values):
  * byte offsets of S, C, Q, E, A, Z, R, ZS in the workspace (order of `which` above), then the byte stride between two
- * feature-quad rows and between two layers.  Every offset and both strides are multiples of 256: a lane quarter's 256-byte
- * segment is exactly two cache lines (tests/test_cabi_symbols.py holds the layout to that). */
+ * feature-quad rows and between two layers OF THE fp32 ARRAYS.  Every offset and both strides are multiples of 256: a lane
+ * quarter's 256-byte segment is exactly two cache lines (tests/test_cabi_symbols.py holds the layout to that). */
 int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, int64_t* out);
+
+/* Format of the stash a training workspace of this network keeps between the sweeps and the weight-gradient GEMM
+ * (the activations `backward()` needs — what autograd saves for reference src/model.py:116-135 / src/diff_operators.py:208-212):
+ *   0 = every array fp32, [layer][feature/4][column][4];
+ *   1 = the arrays only the backward reads (S, Q, R, E, A, Z) hold fp32 values rounded to 24 bits (relative error <= 2^-17),
+ *       12 bytes per 4 values, tile-major [layer][feature/16][column/16][64 lanes][3 dwords]; C and ZS stay fp32.
+ * Selected per network by the library (DUDF_STASH=17|17p24; 24 bits need the fp16x3 kernels of 256-wide layers); -1 = bad cfg.
+ * dudf_debug_read_stash decodes either. */
+int dudf_stash_mode(const dudf_net_cfg* cfg);
 
 /* One training batch on the GPU — replaces `sampleTrainingData` (reference src/dataset.py:14-70, open3d on the CPU)
  * for a triangle soup tri (n_tri,9) and its precomputed surface cloud pc_pos/pc_nrm (n_pc,3) (reference

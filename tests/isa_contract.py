@@ -107,6 +107,8 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
     txt = open(asm_path).read()
     if kernel == "f16":        # the fp16x3 build of the same body
         m = re.search(r"^(_ZN\w*wgrad_hidden_f16p_kernelILi256ELi%dE\w*):" % var, txt, re.M)
+    elif kernel == "f16p24":   # ... reading 24-bit tile-major operands: dwordx3 staging loads
+        m = re.search(r"^(_ZN\w*wgrad_hidden_f16p24_kernelILi256ELi%dE\w*):" % var, txt, re.M)
     elif kernel == "q":        # the fragment-prefetching kernel: two register sets (8 loads) per pass of its two-stage loop
         m = re.search(r"^(_ZN\w*wgrad_hidden_bf16q_kernelILi256E\w*):", txt, re.M)
     else:
@@ -122,8 +124,9 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
         else:
             cur.append(t)
     blocks.append((name, cur))
-    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= (60 if kernel == "f16" else 90)
-           and any(x.startswith("global_load_dwordx4") for x in b)]
+    ldop = "global_load_dwordx3" if kernel == "f16p24" else "global_load_dwordx4"
+    hot = [(n, b) for n, b in blocks if sum(1 for x in b if x.startswith("v_mfma")) >= (60 if kernel.startswith("f16") else 90)
+           and any(x.startswith(ldop) for x in b)]
     assert len(hot) == 1, [n for n, _ in hot]
     name, blk = hot[0]
     assert any(x.startswith("s_cbranch") and x.endswith(name) for x in blk), "the hot block must loop onto itself"
@@ -139,7 +142,7 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
                 continue
             if not t or t[0] in ";.":
                 continue
-            if t.startswith("global_load_dwordx4"):
+            if t.startswith(ldop):
                 assert in_asm, "a compiler-issued load inside the hand-counted loop: " + t
                 fifo.append(_vregs(t.split(",")[0]))
                 loads += 1
@@ -163,7 +166,7 @@ def analyse_wgrad_presplit(asm_path, var=0, kernel="p"):
     return {"bad": bad1 + bad2, "loads": loads, "carried": carried, "scratch": scratch}
 
 
-def analyse_f16(asm_path, width=256):
+def analyse_f16(asm_path, width=256, family="f16"):
     """fp16x3 sweep kernels (sweep_f16*_kernel in dudf_sweep_bf16.hip).  The order of a step's vector-memory operations
     differs between the two halves of a workgroup and from the bf16x6 kernels (the tail — and its stash stores — may run in
     front of the step's DMA pieces), so the check replays the FIFO instead of comparing against a formula: vmcnt retires in
@@ -173,7 +176,8 @@ def analyse_f16(asm_path, width=256):
     slack = how many more operations the wait could have left in flight (0 = as loose as safety allows)."""
     txt = open(asm_path).read()
     out = {}
-    for m in re.finditer(r"^(_ZN\w*sweep_f16_(?:np_)?kernelILi%dELi(\d)ELi(\d)E\w*):[^\n]*$" % width, txt, re.M):
+    # family "f16p": the builds with the 24-bit tile-major stash (sweep_f16p*_kernel: dwordx3 stash accesses, same step structure)
+    for m in re.finditer(r"^(_ZN\w*sweep_%s_(?:np_)?kernelILi%dELi(\d)ELi(\d)E\w*):[^\n]*$" % (family, width), txt, re.M):
         body = txt[m.end():txt.index("s_endpgm", m.end())]
         in_asm, scratch, fifo, waits, epoch = False, 0, [], [], 0
         for ln in body.split("\n"):

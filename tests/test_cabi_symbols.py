@@ -36,10 +36,14 @@ def test_host_only_calls():
     assert lib.dudf_theta_count(ctypes.byref(cfg)) == 461825
     nb = lib.dudf_workspace_bytes(ctypes.byref(cfg), 29970)
     np_ = (29970 + 63) // 64 * 64
-    assert nb >= 7 * 8 * 256 * np_ * 4
+    # seven stash arrays per layer and column: all fp32 (mode 0), or six of them at 3 bytes per value + C at 4 (mode 1)
+    per_value = {0: 7 * 4, 1: 6 * 3 + 4}[lib.dudf_stash_mode(ctypes.byref(cfg))]
+    assert nb >= per_value * 8 * 256 * np_
     nbh = lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 29970, 9990)       # on-surface third on the Hessian path
     cols = (4 * 9990 + 63) // 64 * 64 + (19980 + 63) // 64 * 64
-    assert nbh >= 8 * 8 * 256 * cols * 4
+    assert nbh >= (per_value + 4) * 8 * 256 * cols                            # + ZS (fp32)
+    assert lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 512, 30.0))) == 0   # 512-wide layers relay their operands through the stash: fp32
+    assert lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 100, 30.0))) == -1
     assert lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 10, 11) == 0
     bad = _lib.NetCfg(3, 8, 100, 30.0)
     assert lib.dudf_theta_count(ctypes.byref(bad)) == -1

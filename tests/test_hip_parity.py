@@ -290,7 +290,7 @@ np.savez(sys.argv[1], terms=terms.cpu().numpy(), g=g.cpu().numpy(), f=f.cpu().nu
     assert rel(outs["fp16"]["g"], outs["bf16"]["g"]) < 5e-6
 
 
-@pytest.mark.parametrize("scale", [1e-12, 1e-4, 1.0, 1e6, 1e12])
+@pytest.mark.parametrize("scale", [1e-12, 1e-4, 1.0, 1e6, 1e12, 2.0 ** -40, 2.0 ** 40])
 def test_fp16x3_range_scaling(hip, scale):
     """fp16x3 buys fp16's range with powers of two: per matrix (weights), per column (the sweeps' B operands), per layer
     (the weight-gradient GEMM's operands).  The backward is linear in the upstream cotangent, so scaling `cot` by 1e-12 ...
@@ -306,7 +306,11 @@ def test_fp16x3_range_scaling(hip, scale):
     g1 = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.ones(4, device="cuda"), None, ws).clone()
     gs = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.full((4,), scale, device="cuda"), None, ws)
     assert torch.isfinite(gs).all()
-    assert rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy()) < 2e-6, scale
+    # 2e-6: fp32's own noise at 700 points.  With the 24-bit stash (dudf_stash_mode 1) a cotangent scaled by a NON-power of two
+    # rounds the stashed adjoints at other places — 2^-17 = 7.6e-6 per element, the format's bound, is then the bar for this
+    # self-consistency check (measured 2.0e-6); powers of two commute with the rounding and keep the fp32 bar.
+    pow2 = float(np.log2(scale)).is_integer()
+    assert rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy()) < (2e-6 if pow2 or hip.stash_mode(cfg) == 0 else 8e-6), scale
     if scale in (1e-4, 1e6):                             # weights far from the init's size: oracle-direct
         k = 4.0 if scale > 1 else 1.0 / 64.0
         P2 = [(w * (k if 0 < i < len(P) - 1 else 1.0), b) for i, (w, b) in enumerate(P)]

@@ -107,6 +107,18 @@ def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
             # strict (the other sweeps' operand waits, placed by the compiler, retire the older DMA pieces anyway)
             if key[0] == 0 and force == 0:
                 assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
+    # the builds that keep the backward-only stash arrays at 24 bits (training variants of the plain columns and of the quads):
+    # same step structure, dwordx3 stash accesses — the same replay must hold
+    for force in (0, 1):
+        res = analyse_f16(bf16_asm[f"late{force}"], family="f16p")
+        assert set(res) == {(0, 3), (1, 1), (2, 0), (3, 1), (3, 0), (4, 1), (5, 1), (6, 0), (7, 0)}, sorted(res)
+        for key, v in res.items():
+            assert len(v["waits"]) >= 8, (force, key, v["waits"])
+            for n, late, slack in v["waits"]:
+                assert late == 0, f"late={force} sweep_f16p_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) leaves {late} pieces of the next chunk in flight"
+    ship24 = analyse_f16(bf16_asm["ship"], family="f16p")
+    assert len(ship24) == 9 and all(v["scratch_hot"] == 0 and v["scratch"] <= 10 for v in ship24.values()), \
+        {k: (v["scratch"], v["scratch_hot"]) for k, v in ship24.items()}
     ship = analyse_f16(bf16_asm["ship"])                # the shipped kernels (both orders behind a wave-uniform branch): nothing spills inside a loop (a few dwords of cold address spills in the prologue are tolerated)
     assert len(ship) == 15 and all(v["scratch_hot"] == 0 and v["scratch"] <= 8 for v in ship.values()), \
         {k: (v["scratch"], v["scratch_hot"]) for k, v in ship.items()}
@@ -137,4 +149,12 @@ def test_wgrad_register_staging_contract(tmp_path):
     # the fp16x3 build of the same body (round 3: the default): same contract
     res = analyse_wgrad_presplit(asm, 9, "f16")
     assert res["loads"] == 12 and res["carried"] == 12 and not res["bad"] and res["scratch"] == 0, res
+    # ... and of the build that reads 24-bit tile-major operands (dwordx3 staging loads, transposed LDS fragment reads)
+    res = analyse_wgrad_presplit(asm, 9, "f16p24")
+    assert res["loads"] == 12 and res["carried"] == 12 and not res["bad"] and res["scratch"] == 0, res
+    txt = open(asm).read()
+    import re
+    m = re.search(r"^(_ZN\w*wgrad_hidden_f16p24_kernelILi256ELi9E\w*):", txt, re.M)
+    body = txt[m.end():re.compile(r"^\.Lfunc_end\d+:", re.M).search(txt, m.end()).start()]
+    assert body.count("ds_read_b64_tr_b16") >= 24 and "global_load_dwordx4" not in body
 
