@@ -22,7 +22,7 @@ _ERRORS = {
 
 class NetCfg(ctypes.Structure):
     _fields_ = [("n_in", ctypes.c_int32), ("n_hidden_layers", ctypes.c_int32),
-                ("hidden", ctypes.c_int32), ("w0", ctypes.c_float)]
+                ("hidden", ctypes.c_int32), ("w0", ctypes.c_float), ("ww", ctypes.c_float)]     # ww = 0: the same as w0
 
 
 class DudfError(RuntimeError):

@@ -99,7 +99,7 @@ int check_ws(const DudfLayout& lo, const void* ws, size_t bytes) {
 
 SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     SweepArgs a;
-    a.theta = theta; a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt;
+    a.theta = theta; a.w1b = ws + lo.ws_w1b; a.b1s = ws + lo.ws_b1s; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt;
     a.wimg_f = reinterpret_cast<const char*>(ws + lo.ws_wimg);
     a.wimg_t = a.wimg_f + (size_t)(lo.L - 1) * lo.H * lo.H * 6;
     a.wimg16_f = reinterpret_cast<const char*>(ws + lo.ws_wimg16);
@@ -242,7 +242,7 @@ int backward_sweeps(Ctx& c, const float* theta, int have_g, bool zeroed) {
 extern "C" {
 
 const char* dudf_version(void) {
-    return "dudf_hip 0.4 (gfx950: fp16x3 / bf16x6 MFMA sweeps and weight-gradient GEMM at fp32 accuracy, f32-input MFMA variants, "
+    return "dudf_hip 0.5 (gfx950: fp16x3 / bf16x6 MFMA sweeps and weight-gradient GEMM at fp32 accuracy, f32-input MFMA variants, "
            "Hessian quads, third-order jets, GPU sampler, ray marching)";
 }
 
@@ -624,7 +624,8 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
     const DudfLayout& lo = c.lo;
     const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
     if (which < 0 || which > 7) return DUDF_E_BADMODE;
-    const bool b24 = lo.p24 && which != 1 && which != 7;          // S, Q, E, A, Z, R: 24-bit tile-major in a p24 workspace
+    // S, Q, A, Z | E, R: 24-bit tile-major in a p24 workspace (DUDF_P24_ARRAYS)
+    const bool b24 = lo.p24 && which != 1 && which != 7 && (DUDF_P24_ARRAYS & ((which == 3 || which == 6) ? 2 : 1));
     return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st, which == 1, b24);   // C: one copy per quad
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/dudf_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -26,8 +27,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   the remaining n - n_h points; both padded to whole 128-column tiles with zero columns.
 //
 // workspace:
-//   w1b    [H][4]      = [W_1 | b_1]        A-operand of the first layer (bias folded in as k=3)
-//   w1t16  [16][H]     rows 0..2 = W_1^T, rest 0: A-operand of the last reverse step (df/dx)
+//   w1b    [H][4]      = rho [W_1 | b_1]    A-operand of the first layer (bias folded in as k=3); rho = w0 / ww (1 unless ww != w0)
+//   b1s    [H]         = rho b_1
+//   w1t16  [16][H]     rows 0..2 = rho W_1^T, rest 0: A-operand of the last reverse step (df/dx)
 //   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps (f32 kernel)
 //   wimg   bf16x3 images of W_l, then of W_l^T, in A-fragment order (dudf_sweep_bf16.hip)
 //   wimg16 fp16 hi/lo images of 2^k_l W_l, then of 2^k_l W_l^T (same order, two pieces; "fp16x3" split)
@@ -58,8 +60,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //     byte offset of granule (layer, f, p) = (((layer*(H/16) + f/16)*(np/16) + p/16)*64 + 16*((f%16)/4) + p%16)*12
 // dwords of a granule (values v0..v3 = features 4q..4q+3, u_i = bits(v_i) + 0x80):
 //     d0 = u0>>8 | u1.byte1<<24,  d1 = u1>>16 | (u2>>8)<<16,  d2 = u2.byte3 | (u3>>8)<<8
+#ifndef DUDF_P24_ARRAYS
+#define DUDF_P24_ARRAYS 3     // which arrays a p24 workspace keeps at 24 bits: bit 0 = S, Q, A, Z (the weight-gradient GEMM's operands), bit 1 = R, E
+#endif
 struct DudfLayout {
     int H, L;
+    float rho;               // w0 / ww (dudf_net_cfg): the first layer is packed times rho, `w0` below is the ONE frequency the kernels run (ww)
     int p24;                 // 1: S, Q, R, E, A, Z are 24-bit tile-major arrays (see above)
     float w0;
     int64_t n, n_h;          // points, and how many of them (the first n_h) take the Hessian path
@@ -69,7 +75,7 @@ struct DudfLayout {
     // theta
     int64_t off_w1, off_b1, off_hid, hid_stride, off_wo, off_bo, n_theta;
     // workspace
-    int64_t ws_w1b, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_ebound, ws_zbound, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
+    int64_t ws_w1b, ws_b1s, ws_w1t16, ws_wt, ws_wimg, ws_wimg16, ws_wsc, ws_amax, ws_ebound, ws_zbound, ws_x4, ws_y, ws_g, ws_ybar, ws_gbar;
     int64_t ws_S, ws_C, ws_ZS, ws_Q, ws_R, ws_E, ws_A, ws_Z, ws_acc;
     int64_t stash_layer;     // H*np: floats per layer in a stash array (p24 arrays: 3/4 of that, H*np*3 BYTES)
     size_t total_bytes;
@@ -84,7 +90,9 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     const int H = cfg->hidden, L = cfg->n_hidden_layers;
     if (!(H == 32 || H == 64 || H == 128 || H == 256 || H == 512)) return DUDF_E_BADCFG;
     if (n < 0 || n_h < 0 || n_h > n) return DUDF_E_BADCFG;
-    lo->H = H; lo->L = L; lo->w0 = cfg->w0;
+    if (!(cfg->w0 > 0.f) || cfg->ww < 0.f) return DUDF_E_BADCFG;
+    const float ww = cfg->ww > 0.f ? cfg->ww : cfg->w0;
+    lo->H = H; lo->L = L; lo->w0 = ww; lo->rho = cfg->w0 / ww;
     lo->n = n; lo->n_h = n_h;
     lo->p24 = (!query_only && dudf_stash_p24_enabled(H, L)) ? 1 : 0;
     auto pad = [](int64_t c) { return (c + DUDF_COL_PAD - 1) / DUDF_COL_PAD * DUDF_COL_PAD; };
@@ -108,8 +116,12 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     // 256-byte segment of a stash row is then exactly two 128-byte lines.  (Round 3 first put two small arrays of 64 + 128 bytes
     // in front of the stash: every segment straddled three lines, and FETCH_SIZE / WRITE_SIZE of all four sweeps read 9-12 %
     // above the algorithmic bytes until this was noticed — profiles/r03_a, r03_b against r02_c.)
-    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64; return r; };
+    // DUDF_STASH_SKEW=<n> (experiment): n * 256 bytes of padding behind every array, so that the stash arrays a sweep streams
+    // together do not sit at identical offsets modulo the HBM channel / bank interleave
+    static const int64_t skew = [] { const char* e = getenv("DUDF_STASH_SKEW"); return e ? (int64_t)atoi(e) * 64 : (int64_t)0; }();
+    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64 + skew; return r; };
     lo->ws_w1b = take(4 * (int64_t)H);
+    lo->ws_b1s = take((int64_t)H);                                 // rho b_1, contiguous (the forward tails' bias of the first layer)
     lo->ws_w1t16 = take(16 * (int64_t)H);
     lo->ws_wt = take((int64_t)(L - 1) * H * H);
     lo->ws_wimg = take((int64_t)(L - 1) * H * H * 3);      // bf16x3 images of W_l and W_l^T: 2 x 6 bytes per weight
@@ -125,13 +137,14 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
     lo->stash_layer = (int64_t)H * lo->np;
     const int64_t stash = (int64_t)L * lo->stash_layer;
-    const int64_t stash_b = lo->p24 ? stash / 4 * 3 : stash;       // the backward-only arrays: 12 instead of 16 bytes per granule
+    const int64_t stash_b = (lo->p24 && (DUDF_P24_ARRAYS & 1)) ? stash / 4 * 3 : stash;   // the backward-only arrays: 12 instead of 16 bytes per granule
+    const int64_t stash_r = (lo->p24 && (DUDF_P24_ARRAYS & 2)) ? stash / 4 * 3 : stash;   // R, E
     lo->ws_S = take(stash_b); lo->ws_C = take(stash);
     lo->ws_ZS = n_h > 0 ? take(stash) : lo->ws_S;
     if (query_only) {        // value / df/dx / Hessian queries only ever touch S, C, ZS: 16-24 KB per column instead of 56-64
         lo->ws_Q = lo->ws_R = lo->ws_E = lo->ws_A = lo->ws_Z = lo->ws_S;
     } else {
-        lo->ws_Q = take(stash_b); lo->ws_R = take(stash_b); lo->ws_E = take(stash_b); lo->ws_A = take(stash_b);
+        lo->ws_Q = take(stash_b); lo->ws_R = take(stash_r); lo->ws_E = take(stash_r); lo->ws_A = take(stash_b);
         lo->ws_Z = take(stash_b);
     }
     lo->ws_acc = take(2 * DUDF_NACC);
@@ -150,7 +163,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
 struct SweepArgs {
-    const float* theta; const float* w1b; const float* w1t16; const float* wt;
+    const float* theta; const float* w1b; const float* b1s; const float* w1t16; const float* wt;   // b1s: rho b_1 (first-layer bias as packed)
     const char* wimg_f; const char* wimg_t;   // bf16x3 weight images (forward / transposed), dudf_sweep_bf16.hip
     const char* wimg16_f; const char* wimg16_t;   // fp16 hi/lo weight images, scaled by 2^k_l per matrix
     const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l

@@ -5,8 +5,8 @@
 namespace {
 
 // ---- pack: A-operand forms of theta --------------------------------------------------------------
-__global__ void pack_kernel(const float* __restrict__ theta, float* __restrict__ w1b, float* __restrict__ w1t16,
-                            float* __restrict__ wt, int H, int L, int64_t off_hid, int64_t hid_stride) {
+__global__ void pack_kernel(const float* __restrict__ theta, float* __restrict__ w1b, float* __restrict__ b1s, float* __restrict__ w1t16,
+                            float* __restrict__ wt, int H, int L, int64_t off_hid, int64_t hid_stride, float rho) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_wt = (int64_t)(L - 1) * H * H;
     if (gid < n_wt) {                                   // wt[j][i][o] = W_{j+2}[o][i]
@@ -16,11 +16,12 @@ __global__ void pack_kernel(const float* __restrict__ theta, float* __restrict__
     }
     if (gid < 4 * (int64_t)H) {                         // w1b[f][k] = k<3 ? W_1[f][k] : b_1[f]
         const int f = (int)(gid / 4), k = (int)(gid % 4);
-        w1b[gid] = k < 3 ? theta[f * 3 + k] : theta[3 * H + f];
+        w1b[gid] = rho * (k < 3 ? theta[f * 3 + k] : theta[3 * H + f]);
+        if (k == 3) b1s[f] = rho * theta[3 * H + f];
     }
     if (gid < 16 * (int64_t)H) {                        // w1t16[r][f] = r<3 ? W_1[f][r] : 0
         const int r = (int)(gid / H), f = (int)(gid % H);
-        w1t16[gid] = r < 3 ? theta[f * 3 + r] : 0.f;
+        w1t16[gid] = r < 3 ? rho * theta[f * 3 + r] : 0.f;
     }
 }
 
@@ -638,8 +639,8 @@ int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStr
     DudfProfScope prof(PROF_PACK, st);
     int64_t n = (int64_t)(lo.L - 1) * lo.H * lo.H;
     if (n < 16 * (int64_t)lo.H) n = 16 * (int64_t)lo.H;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, ws + lo.ws_w1b,
-                       ws + lo.ws_w1t16, ws + lo.ws_wt, lo.H, lo.L, lo.off_hid, lo.hid_stride);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, ws + lo.ws_w1b, ws + lo.ws_b1s,
+                       ws + lo.ws_w1t16, ws + lo.ws_wt, lo.H, lo.L, lo.off_hid, lo.hid_stride, lo.rho);
     return (int)hipGetLastError();
 }
 

@@ -58,6 +58,12 @@
 #ifndef DUDF_TAILSEQ
 #define DUDF_TAILSEQ 0
 #endif
+#ifndef DUDF_W_RELAY_NT
+#define DUDF_W_RELAY_NT 0                    // 512-wide kernel: 1 = non-temporal stores for the relay array as well (rounds 2-3)
+#endif
+#ifndef DUDF_QT
+#define DUDF_QT 1                            // fp16x3 forward sweep of the plain columns: sine argument in quarter turns from ONE FMA (A/B: 0)
+#endif
 #ifndef DUDF_TAIL_TOP
 #define DUDF_TAIL_TOP (SP != 0 && BS == SWEEP_FWD)   // early half: tail in front of the step's DMA pieces
 #endif
@@ -247,6 +253,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     const bool isv = !HS || (is_jet(SW) ? li == 0 : (lane & 3) == 0);   // value channel (always, on the plain path)
     const int nhid = a.L - 1;                          // hidden x hidden layers (>= 1 here)
     constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
+    const float kQT = DUDF_QT ? a.w0 * 0.636619772367581343f : 1.f;   // fp16x3 forward sweep of the plain columns: pre-activations in quarter turns
 
     f32x4 acc[G::NT], prev[G::NT];                     // this layer's accumulators / the previous layer's, tails pending
     const int64_t p = (int64_t)(g_first + wave) * 16 + li;
@@ -349,7 +356,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {   // forward sweep: b_{layer+1}
-        return layer == 0 ? a.theta + 3 * H : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;
+        return layer == 0 ? a.b1s : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;   // (b1s: rho b_1 as packed)
     };
     auto stash_base = [&](int layer, int T) -> int64_t {              // wave-uniform, and told so: SGPR base + lane offset
         const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
@@ -381,9 +388,10 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             const f32x4 us = {unscale, unscale, unscale, unscale};
             e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
             e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
-        } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
-            e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+        } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: w0 z 2/pi = (2^-k w0 2/pi) (2^k W h) + (w0 2/pi) b: one FMA per value,
+            const float uq = unscale * kQT;                 // in quarter turns (the biases in LDS carry the factor: sweep_body_b)
+            e0 = epilogue<SW, FL, false, P24 != 0, DUDF_QT != 0>(a, __builtin_elementwise_fma(z0, f32x4{uq, uq, uq, uq}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24 != 0, DUDF_QT != 0>(a, __builtin_elementwise_fma(z1, f32x4{uq, uq, uq, uq}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
             e0 = epilogue<SW, FL, false, P24 != 0>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
             e1 = epilogue<SW, FL, false, P24 != 0>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
@@ -859,9 +867,9 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                   // ONE tail pair per wave and layer
             f32x4 z = prev[u];
-            if constexpr (BS == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[u]);
+            if constexpr (BS == SWEEP_FWD) { const float uq = DUDF_QT ? unscale * (a.w0 * 0.636619772367581343f) : unscale; z = __builtin_elementwise_fma(z, f32x4{uq, uq, uq, uq}, bs[u]); }
             else z *= unscale;
-            e[u] = epilogue<SW, FL, kTrackE, P24 != 0>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
+            e[u] = epilogue<SW, FL, kTrackE, P24 != 0, BS == SWEEP_FWD && DUDF_QT != 0>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
         }
         if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) lds_max_wave(lds_amax + lin, tk.t); tk.t = 0.f; }
         if constexpr (kTrackE) {
@@ -974,9 +982,11 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, 
     if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }   // (sweep_tile_b starts with a barrier)
     if constexpr (SP != 0 && base_of(SW) == SWEEP_FWD) {     // b_1 .. b_L behind the three weight buffers (read by the tails)
         float* lb = reinterpret_cast<float*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
+        // plain columns: times w0 2/pi — their tail forms the sine's argument in quarter turns with one FMA (dudf_sincos_quarter)
+        const float bq = (DUDF_QT && SW == SWEEP_FWD) ? a.w0 * 0.636619772367581343f : 1.f;
         for (int i = threadIdx.x; i < a.L * H; i += 64 * NWB) {
             const int layer = i / H, f = i - layer * H;
-            lb[i] = layer == 0 ? a.theta[3 * H + f] : a.theta[a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H + f];
+            lb[i] = bq * (layer == 0 ? a.b1s[f] : a.theta[a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H + f]);
         }
     }
     // the two waves of a SIMD (w, w + 4) leave every k-block barrier in lockstep: tails coincide, MFMA streams collide.
@@ -1142,7 +1152,8 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__
 // launched pack, pack_bf16, x4 and two memsets separately: ~5 us each, 1.7 % of a 3.5 ms step).  Block roles by index range.
 struct PrepArgs {
     const float* theta; const float* x;
-    float *w1b, *w1t16, *wt, *x4, *wsc;
+    float *w1b, *b1s, *w1t16, *wt, *x4, *wsc;
+    float rho;                                          // w0 / ww: the first layer as the kernels see it
     char *img16_f, *img16_t, *img_f, *img_t;
     unsigned* zero; int nzero;                          // the loss sums + ticket and the running maxima: nzero dwords from `zero`
     unsigned* zero2; int nzero2;
@@ -1180,9 +1191,13 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     b -= a.nb_x4;
     if (b < a.nb_thin) {                                 // w1b[f][k] = k<3 ? W_1[f][k] : b_1[f];  w1t16[r][f] = r<3 ? W_1[f][r] : 0;  zeros
         for (int gid = b * 256 + threadIdx.x; gid < 16 * H; gid += a.nb_thin * 256) {
-            if (gid < 4 * H) { const int f = gid / 4, k = gid % 4; a.w1b[gid] = k < 3 ? a.theta[f * 3 + k] : a.theta[3 * H + f]; }
+            if (gid < 4 * H) {
+                const int f = gid / 4, k = gid % 4;
+                a.w1b[gid] = a.rho * (k < 3 ? a.theta[f * 3 + k] : a.theta[3 * H + f]);
+                if (k == 3) a.b1s[f] = a.rho * a.theta[3 * H + f];
+            }
             const int r = gid / H, f = gid % H;
-            a.w1t16[gid] = r < 3 ? a.theta[f * 3 + r] : 0.f;
+            a.w1t16[gid] = r < 3 ? a.rho * a.theta[f * 3 + r] : 0.f;
         }
         if (b == 0) {
             for (int i = threadIdx.x; i < a.nzero; i += 256) a.zero[i] = 0u;
@@ -1398,7 +1413,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     float unscale = 1.f, sb = 1.f, inv_sb = 1.f;        // accumulators -> true values | scale of the B operand being read back
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {
-        return layer == 0 ? a.theta + 3 * H : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;
+        return layer == 0 ? a.b1s : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;   // (b1s: rho b_1 as packed)
     };
     auto stash_base = [&](int layer, int T) -> int64_t {
         const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
@@ -1468,8 +1483,9 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             else if constexpr (SW == SWEEP_FWD) z += bs[s];
             else if constexpr (BS == SWEEP_FWD) z = (SP != 0 ? z * unscale : z) + (isv ? bs[s] : zero4);   // the bias: value channel only
             else if constexpr (SP != 0) z *= unscale;
-            const f32x4 e = epilogue<SW, FL>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
-            if constexpr (wide_relay_store<SW, FL>()) DUDF_ST(a.S, stash_base(layer, T), vo, e);
+            // (RL: the array the next layer reads its operand back from keeps the default cache policy — DUDF_W_RELAY_NT=1: A/B)
+            const f32x4 e = epilogue<SW, FL, false, false, false, !DUDF_W_RELAY_NT>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
+            if constexpr (wide_relay_store<SW, FL>()) { if constexpr (DUDF_W_RELAY_NT) DUDF_ST(a.S, stash_base(layer, T), vo, e); else DUDF_ST_CACHED(a.S, stash_base(layer, T), vo, e); }
             if constexpr (kColScale) dudf_track(cmax, e);
             if (T + PD < G::NT) ld(T + PD, s);
             if (last) {
@@ -1861,7 +1877,7 @@ template <int H>
 int prep_b(const DudfLayout& lo, const float* theta, const float* x, float* ws, int need, hipStream_t st) {
     PrepArgs a;
     a.theta = theta; a.x = x;
-    a.w1b = ws + lo.ws_w1b; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt; a.x4 = ws + lo.ws_x4; a.wsc = ws + lo.ws_wsc;
+    a.w1b = ws + lo.ws_w1b; a.b1s = ws + lo.ws_b1s; a.rho = lo.rho; a.w1t16 = ws + lo.ws_w1t16; a.wt = ws + lo.ws_wt; a.x4 = ws + lo.ws_x4; a.wsc = ws + lo.ws_wsc;
     a.img_f = reinterpret_cast<char*>(ws + lo.ws_wimg); a.img_t = a.img_f + (size_t)(lo.L - 1) * GeoB<H>::IMGB;
     a.img16_f = reinterpret_cast<char*>(ws + lo.ws_wimg16); a.img16_t = a.img16_f + (size_t)(lo.L - 1) * GeoB<H, 1>::IMGB;
     a.zero = reinterpret_cast<unsigned*>(ws + lo.ws_acc); a.nzero = 2 * DUDF_NACC;

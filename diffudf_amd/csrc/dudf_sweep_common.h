@@ -43,6 +43,30 @@ __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2&
     }
 }
 
+// ... for an argument in quarter turns (dudf_sincos_quarter: the fp16x3 forward sweep of the plain columns)
+__device__ __forceinline__ void dudf_sincos2_q(dudf_f2 t, dudf_f2& s_out, dudf_f2& c_out) {
+#if DUDF_SWEEP_DBG & 64
+    s_out = t; c_out = t * 0.5f; return;
+#endif
+    const dudf_f2 k = {rintf(t.x), rintf(t.y)};
+    const dudf_f2 d = t - k;
+    const dudf_f2 r = __builtin_elementwise_fma(d, (dudf_f2)(1.57079637050628662109375f), d * (dudf_f2)(-4.37113900018624283e-8f));
+    const dudf_i2 n = {(int)k.x, (int)k.y};
+    const dudf_f2 r2 = r * r;
+    dudf_f2 ps = __builtin_elementwise_fma(r2, (dudf_f2)(-1.9515295891e-4f), (dudf_f2)(8.3321608736e-3f));
+    ps = __builtin_elementwise_fma(r2, ps, (dudf_f2)(-1.6666654611e-1f));
+    const dudf_f2 sr = __builtin_elementwise_fma(r * r2, ps, r);
+    dudf_f2 pc = __builtin_elementwise_fma(r2, (dudf_f2)(2.443315711809948e-5f), (dudf_f2)(-1.388731625493765e-3f));
+    pc = __builtin_elementwise_fma(r2, pc, (dudf_f2)(4.166664568298827e-2f));
+    const dudf_f2 cr = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (dudf_f2)(-0.5f), (dudf_f2)(1.0f)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float so, co;
+        dudf_quadrant(n[i], sr[i], cr[i], &so, &co);
+        s_out[i] = so; c_out[i] = co;
+    }
+}
+
 // Stash addressing: `ub` is a WAVE-UNIFORM float offset (layer and tile folded in, lives in SGPRs),
 // `vo` the lane's 32-bit float offset ((quarter*np + point)*4): global_load/store take the saddr form
 // and no per-tile 64-bit address is kept in VGPRs.
@@ -114,8 +138,17 @@ __device__ __forceinline__ dudf_u3 dudf_dbg_any3() { dudf_u3 z; asm volatile("" 
 #else
 #define DUDF_LD24(arr, ub, vt) p24_unpack(__builtin_nontemporal_load(DUDF_CAT24(arr, ub, vt)))
 #endif
+// default cache policy (no `nt`): the 512-wide kernel reads an array it has just written back as the next layer's operand
+// (sweep_tile_w: the "relay"); with the hint the line has left L2 by then (config 3: -2.3 % step time without it on the relay)
+#if DUDF_SWEEP_DBG & 1
+#define DUDF_ST_CACHED(arr, ub, vo, val) asm volatile("" :: "v"((f32x4)(val)))
+#else
+#define DUDF_ST_CACHED(arr, ub, vo, val) (*DUDF_AT(arr, ub, vo) = (f32x4)(val))
+#endif
 // a backward-only array in the format of this build: P (compile-time) = 24-bit tile-major, else fp32 rows
 #define DUDF_STB(P, arr, ub, lo, val) do { if constexpr (P) DUDF_ST24(arr, ub, (lo).t, val); else DUDF_ST(arr, ub, (lo).v, val); } while (0)
+// ... or, RL (compile-time): this array is the caller's relay — default cache policy
+#define DUDF_STR(RL, P, arr, ub, lo, val) do { if constexpr (RL) DUDF_ST_CACHED(arr, ub, (lo).v, val); else DUDF_STB(P, arr, ub, lo, val); } while (0)
 #define DUDF_LDB(P, arr, ub, lo) ((P) ? DUDF_LD24(arr, ub, (lo).t) : DUDF_LD(arr, ub, (lo).v))
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
@@ -217,7 +250,9 @@ struct LaneOff {
     __device__ __forceinline__ LaneOff(unsigned x, unsigned y, unsigned z) : v(x), c(y), t(z) {}
 };
 
-template <int SW, int FL, bool TE = false, bool P24 = false>
+// QT (forward sweep only): `acc` is the pre-activation in QUARTER TURNS, w0 z 2/pi (constants folded into the caller's FMA)
+// RL: the array that carries this sweep's post-tail values (S / Q / A / Z by sweep) is stored with the default cache policy
+template <int SW, int FL, bool TE = false, bool P24 = false, bool QT = false, bool RL = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
                                           const LaneOff lo, bool isv, TailTrack& tk) {
     const unsigned vo = lo.v;
@@ -227,27 +262,28 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
             dudf_f2 sv, cv;
-            dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
+            if constexpr (QT) dudf_sincos2_q(dudf_f2{acc[t], acc[t + 1]}, sv, cv);
+            else dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
             s[t] = sv.x; s[t + 1] = sv.y; c[t] = cv.x; c[t + 1] = cv.y;
         }
-        if constexpr (FL & 1) DUDF_STB(P24, a.S, ub, lo, s);
+        if constexpr (FL & 1) DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo, s);
         if constexpr (FL & 2) DUDF_ST(a.C, ub, vo, c);
         out = s;
     } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
         out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
         if constexpr (FL & 1) {
-            DUDF_STB(P24, a.Q, ub, lo, out);
-            DUDF_STB(P24, a.R, ub, lo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
+            DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Q, ub, lo, out);
+            DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
-        DUDF_STB(P24, a.A, ub, lo, out);
+        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.A, ub, lo, out);
         const f32x4 ev = o2 * acc;                   // e_l = r_l Q_l
-        DUDF_STB(P24, a.E, ub, lo, ev);
+        DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo, ev);
         if constexpr (TE) dudf_track(tk.e, ev);      // (per column: what bounds zbar_l in the fp16x3 adjoint reverse sweep)
     } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
-        DUDF_STB(P24, a.Z, ub, lo, out);
+        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Z, ub, lo, out);
     } else if constexpr (SW == SWEEP_FWD_H) {
         f32x4 c, zs;
 #pragma unroll
@@ -260,7 +296,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         DUDF_ST(a.C, ub, lo.c, c);   // one copy per quad (LaneOff): the four lanes hold the same bits and write the same granule — no branch
         DUDF_ST(a.ZS, ub, vo, zs);
-        if constexpr (FL & 1) DUDF_STB(P24, a.S, ub, lo, out);
+        if constexpr (FL & 1) DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo, out);
     } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -268,8 +304,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = isv ? a.w0 * o1[t] * acc[t] : a.w0 * (o1[t] * acc[t] - a.w0 * sv * o2[t] * a0);
         }
         if constexpr (FL & 1) {
-            DUDF_STB(P24, a.Q, ub, lo, out);
-            DUDF_STB(P24, a.R, ub, lo, acc);
+            DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Q, ub, lo, out);
+            DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo, acc);
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {    // o1 = c, o2 = s|zdot^k, o3 = a|adot^k
         f32x4 e;
@@ -286,8 +322,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = a.w0 * (o1[t] * acc[t] + (isv ? s1 : 0.f));
             e[t] = isv ? a.w0 * (o1[t] * sbar - sv * cbar) : -a.w0 * sv * chat;
         }
-        DUDF_STB(P24, a.A, ub, lo, out);
-        DUDF_STB(P24, a.E, ub, lo, e);
+        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.A, ub, lo, out);
+        DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo, e);
         if constexpr (TE) dudf_track(tk.e, e);
     } else if constexpr (SW == SWEEP_FWD_J) {
         const int lane = threadIdx.x & 63, l0 = lane & 48;
@@ -314,7 +350,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             const float st = quad_sum(isv ? 0.f : o2[t] * acc[t]);
             out[t] = o3[t] + a.w0 * o1[t] * acc[t] - (isv ? a.w0 * a.w0 * sv * st : 0.f);
         }
-        DUDF_STB(P24, a.Z, ub, lo, out);
+        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Z, ub, lo, out);
     }
     if constexpr (amax_row<SW, FL>() >= 0) dudf_track(tk.t, out);
     return out;
@@ -327,24 +363,24 @@ __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, c
     const unsigned vo = lo.v;
     if constexpr (SW == SWEEP_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = DUDF_LDB(P24, a.S, ub, lo);
+        if constexpr (FL & 1) o2 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
         o1 = DUDF_LD(a.C, ub, vo);
-        o2 = DUDF_LDB(P24, a.R, ub, lo);
+        o2 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = DUDF_LDB(P24, a.E, ub, lo);      // no df/dx terms (loss_s2): e_l == 0
+        if constexpr (FL & 1) o2 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo);      // no df/dx terms (loss_s2): e_l == 0
     } else if constexpr (SW == SWEEP_REV_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
-        o3 = DUDF_LDB(P24, a.R, ub, lo);
+        o3 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
-        o3 = DUDF_LDB(P24, a.E, ub, lo);
+        o3 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo);
     }
 }
 

@@ -416,6 +416,9 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
 #define DUDF_WG_NT ""
 #endif
 #endif
+#ifndef DUDF_WGRAD_TR_DEFAULT
+#define DUDF_WGRAD_TR_DEFAULT false   // fp32 rows through the [column][feature] image + transposed fragment reads (A/B: DUDF_WGRAD_TR=1)
+#endif
 #ifndef DUDF_WG_HREL
 #define DUDF_WG_HREL 2             // flag-synchronised variant: hand the matrix pipe over this many MFMA groups before the end of a stage
 #endif
@@ -448,6 +451,9 @@ __device__ __forceinline__ int dudf_exp_above(unsigned bits) {     // e with |v|
 }
 __device__ __forceinline__ float dudf_pow2(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
+// P24 = 2: the fp32 row layout read the way the sweeps read it — a wave-instruction takes 256-byte pieces of FOUR feature-quad rows
+// (lane = (q, li): row 16 pw + 4 t + q, column li) instead of 64-byte pieces of sixteen — into the same [column][feature] image
+// and transposed fragment reads as P24 = 1, without the 24-bit decode ("row-major staging").
 // P24 = 1: the operands arrive as 24-bit tile-major stash arrays (dudf_internal.h "p24": [layer][feature tile][16-column group]
 // [64 lanes][3 dwords]).  A 16-column stage of an operand is then 16 contiguous 768-byte blocks, one per feature tile: a wave
 // loads a block with ONE dwordx3 instruction (six full lines), lane (q, li) holding features 16 T + 4 q .. + 3 of column li.
@@ -505,7 +511,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
     // (P24: a layer of a 24-bit array is 3/4 of stash_layer floats; H == Hs, so xrow == yrow == 0)
-    const int64_t lstride = P24 ? a.stash_layer / 4 * 3 : a.stash_layer;
+    const int64_t lstride = P24 == 1 ? a.stash_layer / 4 * 3 : a.stash_layer;
     const float* X0 = a.Q + (int64_t)(j + 1) * lstride + xrow;
     const float* X1 = a.Z + (int64_t)(j + 1) * lstride + xrow;
     const float* Y0 = a.A + (int64_t)j * lstride + yrow;
@@ -529,7 +535,7 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     // image of one piece: [32-feature block][column half][feature in block][8 columns] = the fragment order of the MFMA
     const int p_loff = p_oper * OPERB + (p_fq >> 3) * BLKB + (p_cg >> 1) * HALFB + ((p_fq & 7) * 4) * 16 + (p_cg & 1) * 8;   // + f * 16 + piece * PIECEB
     typedef unsigned u3_t __attribute__((ext_vector_type(3)));
-    typedef typename std::conditional<P24 != 0, u3_t, f32x4>::type raw_t;      // P24: a granule is 3 dwords (four 24-bit values)
+    typedef typename std::conditional<P24 == 1, u3_t, f32x4>::type raw_t;      // P24 = 1: a granule is 3 dwords (four 24-bit values)
     struct RawSet { raw_t g0, g1, g2, g3; };                              // granule j: 4 features of column 4*cg + j (P24: of tile 4 pw + j, column li)
     RawSet R0, R1, R2;                                                    // stage s travels in set s % 3, three stages ahead
     f32x4 bacc = {0.f, 0.f, 0.f, 0.f};                                    // bias gradient partial sums (X operand, zbar pair)
@@ -561,13 +567,23 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     // P24 producer role: wave pw (0..3 of its operand) stages feature tiles 4 pw .. 4 pw + 3; lane = (q, li) as in the sweeps
     const int pw = wave & (NW_ / 2 - 1), p_q = lane >> 4, p_li = lane & 15;
     const int64_t ngrp = a.np >> 4;                                       // 16-column groups per row of tiles
-    const unsigned t_voff0 = (unsigned)(lane * 12 + (int64_t)(4 * pw) * ngrp * 768);   // (dudf_make_layout keeps H * np * 3 below 2^32)
-    const unsigned t_vstep = (unsigned)(ngrp * 768);
+    // P24 = 1: tile 4 pw (+ t) of the tile-major array; P24 = 2: row 16 pw + q (+ 4 t) of the fp32 row layout, column li
+    const unsigned t_voff0 = P24 == 2 ? (unsigned)((((int64_t)(16 * pw + p_q)) * a.np + p_li) * 16)
+                                      : (unsigned)(lane * 12 + (int64_t)(4 * pw) * ngrp * 768);   // (the launcher keeps a layer below 2^32 bytes)
+    const unsigned t_vstep = P24 == 2 ? (unsigned)(4 * a.np * 16) : (unsigned)(ngrp * 768);
     // image write offsets of this lane (row li, unit 16 pw + 4 t + q with its low three bits swizzled): tiles with even / odd t
     const int p_sw = (p_li >> 1) & 7;
     const int t_w0 = p_oper * OPERB + p_li * ROWB + 128 * pw + 8 * (p_q ^ p_sw), t_w1 = p_oper * OPERB + p_li * ROWB + 128 * pw + 8 * ((4 + p_q) ^ p_sw);
     auto load_raw = [&](int it, RawSet& r) {
-        if constexpr (P24 != 0) {
+        if constexpr (P24 == 2) {
+            const uint64_t g0 = (uint64_t)(size_t)(reinterpret_cast<const char*>(pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * (KB * 16));
+            const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
+            const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
+            asm volatile("global_load_dwordx4 %0, %4, %8" DUDF_WG_NT "\n\tglobal_load_dwordx4 %1, %5, %8" DUDF_WG_NT "\n\t"
+                         "global_load_dwordx4 %2, %6, %8" DUDF_WG_NT "\n\tglobal_load_dwordx4 %3, %7, %8" DUDF_WG_NT
+                         : "=&v"(r.g0), "=&v"(r.g1), "=&v"(r.g2), "=&v"(r.g3)
+                         : "v"(t_voff0), "v"(t_voff0 + t_vstep), "v"(t_voff0 + 2 * t_vstep), "v"(t_voff0 + 3 * t_vstep), "s"(sbase) : "memory");
+        } else if constexpr (P24 != 0) {
             const uint64_t g0 = (uint64_t)(size_t)(reinterpret_cast<const char*>(pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * 768);
             const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)g0), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
             const uint64_t sbase = ((uint64_t)hi32 << 32) | lo32;
@@ -587,7 +603,13 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     // outside the steady-state loop (prologue, last stages: conditional loads) the loads are ordinary ones: a conditional
     // asm load makes hipcc merge "loaded" and "not loaded" values with register copies — of registers still in flight
     auto load_raw_plain = [&](int it, RawSet& r) {
-        if constexpr (P24 != 0) {
+        if constexpr (P24 == 2) {
+            const char* src = reinterpret_cast<const char*>(pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * (KB * 16) + t_voff0;
+            r.g0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            r.g1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + t_vstep));
+            r.g2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 2 * (size_t)t_vstep));
+            r.g3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 3 * (size_t)t_vstep));
+        } else if constexpr (P24 != 0) {
             const char* src = reinterpret_cast<const char*>(pair_of(it) ? P1 : P0) + (int64_t)step_of(it) * 768 + t_voff0;
             r.g0 = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(src));
             r.g1 = __builtin_nontemporal_load(reinterpret_cast<const u3_t*>(src + t_vstep));
@@ -683,9 +705,14 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
     // 8-byte writes into row li of the [column][feature] image
     auto split_tile = [&](int it, const raw_t& g, f32x4& bsum, int t, int bsel, const float bmask, const float scl) {
         if constexpr (P24 != 0) {
-            const unsigned d0 = g[0], d1 = g[1], d2 = g[2];
-            const f32x4 v = {__uint_as_float(d0 << 8), __uint_as_float(__builtin_amdgcn_perm(d1, d0, 0x0504030cu)),
-                             __uint_as_float(__builtin_amdgcn_perm(d2, d1, 0x0403020cu)), __uint_as_float(d2 & 0xffffff00u)};
+            f32x4 v;
+            if constexpr (P24 == 1) {
+                const unsigned d0 = g[0], d1 = g[1], d2 = g[2];
+                v = f32x4{__uint_as_float(d0 << 8), __uint_as_float(__builtin_amdgcn_perm(d1, d0, 0x0504030cu)),
+                          __uint_as_float(__builtin_amdgcn_perm(d2, d1, 0x0403020cu)), __uint_as_float(d2 & 0xffffff00u)};
+            } else {
+                v = g;
+            }
             bsum += bmask * v;
             const f32x2 v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
             // hi = fp16(v 2^k) in ONE instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: fp32 sources, fp16 result into one
@@ -986,6 +1013,11 @@ template <int H, int VAR>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_f16p_kernel(WgradArgs a) {
     wgrad_hidden_bf16p_body<H, VAR, 1>(a);
 }
+// ... the fp32 rows staged 4 rows x 256 bytes per wave-instruction, [column][feature] image, transposed fragment reads
+template <int H, int VAR>
+__global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_f16tr_kernel(WgradArgs a) {
+    wgrad_hidden_bf16p_body<H, VAR, 1, 2>(a);
+}
 // ... reading 24-bit tile-major operands (dudf_internal.h "p24")
 template <int H, int VAR>
 __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_hidden_f16p24_kernel(WgradArgs a) {
@@ -1003,6 +1035,7 @@ struct WgradSmallArgs {
     int64_t np, ncols, stash_layer, off_wo, off_bo;
     int H, L, have_g;
     int pts_per_block;
+    float rho;                          // w0 / ww: d(loss)/d(W_1, b_1) = rho d(loss)/d(rho W_1, rho b_1)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -1055,7 +1088,7 @@ __device__ __forceinline__ void wgrad_small_body(const WgradSmallArgs& a) {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const float v = wave_sum(w1[c][d]);
-                if (lane == 0) atomicAdd(d < 3 ? a.dtheta + f * 3 + d : a.dtheta + 3 * a.H + f, v);
+                if (lane == 0) atomicAdd(d < 3 ? a.dtheta + f * 3 + d : a.dtheta + 3 * a.H + f, a.rho * v);
             }
             const float vo = wave_sum(wo[c]);
             if (lane == 0) atomicAdd(a.dtheta + a.off_wo + f, vo);
@@ -1122,7 +1155,7 @@ __global__ __launch_bounds__(256) DUDF_NO_PK void wgrad_small_p24_kernel(WgradSm
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const float v = sum16(w1[c][d]);
-            if (li == 0) atomicAdd(d < 3 ? a.dtheta + f * 3 + d : a.dtheta + 3 * a.H + f, v);
+            if (li == 0) atomicAdd(d < 3 ? a.dtheta + f * 3 + d : a.dtheta + 3 * a.H + f, a.rho * v);
         }
         const float vo = sum16(wo[c]);
         if (li == 0) atomicAdd(a.dtheta + a.off_wo + f, vo);
@@ -1200,6 +1233,20 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     hipLaunchKernelGGL((wgrad_hidden_f16p24_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t, st, a);
                     return (int)hipGetLastError();
                 }
+                static const bool tr = [] { const char* e = getenv("DUDF_WGRAD_TR"); return e ? e[0] != '0' : DUDF_WGRAD_TR_DEFAULT; }();
+                if (tr && dudf_split_fp16() && a.amax && a.L <= 64 && var == 9 && ntz == 1 && !dudf_deterministic()) {
+                    dudf_note_products(PROF_WGRAD_HIDDEN, 3);
+                    static bool attr6 = false;
+                    const size_t smem_t = 3 * (size_t)(2 * 2 * 16 * 576) + 512;
+                    if (!attr6) {
+                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_f16tr_kernel<H, 9>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t);
+                        if (e != hipSuccess) return (int)e;
+                        attr6 = true;
+                    }
+                    hipLaunchKernelGGL((wgrad_hidden_f16tr_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t, st, a);
+                    return (int)hipGetLastError();
+                }
                 if (dudf_split_fp16() && a.amax && a.L <= 64 && var == 9) {       // fp16x3 (DUDF_SPLIT=bf16 keeps bf16x6)
                     dudf_note_products(PROF_WGRAD_HIDDEN, 3);
                     static bool attr4 = false;
@@ -1264,7 +1311,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.amax = reinterpret_cast<const unsigned*>(ws + lo.ws_amax);
     a.clk = dudf_prof_clk(PROF_WGRAD_HIDDEN);
     a.remap_nsplit = 0;
-    a.p24 = lo.p24;
+    a.p24 = lo.p24 && (DUDF_P24_ARRAYS & 1);
     const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
     a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;
@@ -1284,7 +1331,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     WgradSmallArgs s;
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;
-    s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g;
+    s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g; s.rho = lo.rho;
     static const int ppb = [] { const char* e = getenv("DUDF_SMALL_PPB"); const int v = e ? atoi(e) : 4096; return v >= 64 ? v : 4096; }();   // A/B testing: with 16 feature-quad groups 4096 columns per block is best (0.096 ms;
                                                                        // round 1: 1024 columns x 4 groups, 0.156 ms)
     s.pts_per_block = dudf_deterministic() ? (int)lo.ncols : ppb;
@@ -1293,7 +1340,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     static const int gy_env = [] { const char* e = getenv("DUDF_SMALL_GY"); return e ? atoi(e) : 0; }();   // A/B testing
     const int fqn = lo.H / 4;                                              // feature quads; a block's 4 waves take one each per round:
     const int gy = gy_env > 0 ? gy_env : (fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1));   // up to 16 groups -> more loads in flight per CU
-    if (lo.p24) {                                   // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
+    if (lo.p24 && (DUDF_P24_ARRAYS & 1)) {          // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
         s.pts_per_block = (s.pts_per_block + 15) / 16 * 16;
         hipLaunchKernelGGL(wgrad_small_p24_kernel, dim3((unsigned)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block), lo.H / 16), dim3(256), 0, st, s);
         return (int)hipGetLastError();

@@ -24,7 +24,7 @@ LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
 
 class TrainEngine:
     def __init__(self, hidden, theta, w0=30.0, process_group=None, betas=(0.9, 0.999), eps=1e-8, ops=None,
-                 collectives=None):
+                 collectives=None, ww=None):
         """`ops` defaults to the HIP kernels.  It is a parameter only so that the CPU/gloo tests can drive the
         distributed bookkeeping below with a stand-in compute backend; nothing in the product passes it.
         `collectives` (N > 1 ranks): "staggered" = five all-reduces per step (three hidden-layer groups, each behind the
@@ -33,7 +33,7 @@ class TrainEngine:
         numbers; which is faster on xGMI is a latency question the first hardware run has to answer —
         `phase_times()` is there to read it off."""
         self.ops = _hip_ops if ops is None else ops
-        self.cfg = self.ops.make_cfg(hidden, w0)
+        self.cfg = self.ops.make_cfg(hidden, w0) if ww is None else self.ops.make_cfg(hidden, w0, ww=ww)
         n_theta = self.ops.theta_count(self.cfg)
         if theta.numel() != n_theta or theta.dtype != torch.float32:
             raise ValueError(f"theta must be a flat fp32 tensor of {n_theta} elements")

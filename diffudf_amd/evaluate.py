@@ -16,18 +16,26 @@ def evaluate(model, samples, latent_vec=None, max_batch=64 ** 2, output_size=1, 
     whatever `max_batch` says (the reference's 4096-point chunks would be launch-bound on MI355X); results do
     not depend on it.
     """
-    if latent_vec is not None and torch.as_tensor(latent_vec).numel() != 0:
-        raise DudfError("evaluate: latent vectors are not part of the HIP path (no reference config uses them)")
     if output_size != 1:
         raise DudfError("evaluate: output_size must be 1")
-    theta = model.flat_parameters()
+    latent = None if latent_vec is None else torch.as_tensor(latent_vec)
+    if latent is not None and latent.numel() != 0:
+        # [latent | xyz] inputs (reference :19-22): the latent part is a constant of the whole call, so the network is queried as
+        # the 3-input network it is for that vector; `gradients` are d/d(xyz) = the reference's gradient(y, x)[..., k:] (:29)
+        if hessians is not None:
+            raise DudfError("evaluate: hessians with a latent vector — the reference itself fails there (its hessian() differentiates "
+                            "the first three INPUT features, src/diff_operators.py:187-193, and evaluate() then raises a shape error)")
+        if latent.dim() == 2 and latent.shape[0] != 1:
+            raise DudfError("evaluate: one latent vector per call (reference src/evaluate.py:21 repeats latent_vec for every sample)")
+        cfg, theta = model.folded(latent)
+    else:
+        cfg, theta = model.hip_cfg, model.flat_parameters()
     dev = theta.device if device is None else torch.device(device)
     if dev.type != "cuda":
         raise DudfError("evaluate: needs the GPU; there is no CPU fallback path")
     n = samples.shape[0]
     evaluations = np.zeros((n, output_size))
     chunk = max(int(max_batch), 1 << 18) if hessians is None else max(int(max_batch), 1 << 16)
-    cfg = model.hip_cfg
     head = 0
     while head < n:
         tail = min(head + chunk, n)

@@ -28,13 +28,18 @@ def padded_width(hidden):
     return min(b for b in BUILT_WIDTHS if b >= max(hidden))
 
 
-def make_cfg(hidden, w0=30.0, n_in=3, n_out=1):
-    """C-ABI network descriptor of SIREN(3, 1, hidden): L = len(hidden) layers of the padded width."""
+def make_cfg(hidden, w0=30.0, n_in=3, n_out=1, ww=None):
+    """C-ABI network descriptor of SIREN(3, 1, hidden, w0, ww): L = len(hidden) layers of the padded width; `ww` = frequency of
+    the SineLayers behind the first one (reference src/model.py:89-106), None / equal to w0: one frequency.  A network with a
+    latent vector in front of the coordinates (n_in = 3 + k) is queried through `diffudf_amd.evaluate.evaluate`, which folds
+    the latent part into the first layer's bias and arrives here with n_in = 3."""
     hidden = list(hidden)
     if n_in != 3 or n_out != 1 or len(hidden) < 1:
-        raise _lib.DudfError("HIP path supports SIREN(3, 1, [...]) (3-D points, scalar field); got "
-                             f"n_in={n_in}, n_out={n_out}, hidden={hidden}")
-    return NetCfg(3, len(hidden), padded_width(hidden), float(w0))
+        raise _lib.DudfError("HIP path supports SIREN(3, 1, [...]) (3-D points, scalar field; latent-conditioned networks "
+                             f"through evaluate(model, samples, latent_vec)); got n_in={n_in}, n_out={n_out}, hidden={hidden}")
+    if not (float(w0) > 0) or (ww is not None and not (float(ww) > 0)):
+        raise _lib.DudfError(f"SineLayer frequencies must be positive; got w0={w0}, ww={ww}")
+    return NetCfg(3, len(hidden), padded_width(hidden), float(w0), 0.0 if ww is None or float(ww) == float(w0) else float(ww))
 
 
 def sweeps_on_bf16(hidden, layers, w0=30.0):

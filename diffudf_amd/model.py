@@ -19,6 +19,10 @@ What is different inside
     hip_ops.padded_width); the parameters are strided views of it with the CALLER's shapes, so state_dict, optimizers and
     autograd never see a padded entry
   * `forward` runs the fused HIP value sweep; there is no PyTorch/CPU fallback: CPU inputs raise.
+  * `ww != w0` (first SineLayer w0, the others ww): one extra float of the C ABI's network descriptor (round 4)
+  * `n_in_features = 3 + k` (a latent vector in front of the coordinates, reference src/evaluate.py:19-22): such a network is
+    QUERIED — `evaluate(model, samples, latent_vec, ...)` — as the 3-input network it is for that vector (`folded`); training
+    it is not part of the reference's recipes (every `SIREN(...)` the reference constructs has 3 inputs) and raises.
 """
 import math
 import weakref
@@ -192,13 +196,30 @@ class SIREN(nn.Module):
     def hip_cfg(self):
         if self.activation != 'sine':
             raise DudfError("only activation='sine' has a HIP path (the reference's 'relu' variant is unused by its configs)")
-        if self.ww != self.w0:
-            raise DudfError("HIP path needs ww == w0 (every reference config leaves ww=None)")
-        return hip_ops.make_cfg(self.hidden_layer_config, self.w0, self.n_in_features, self.n_out_features)
+        return hip_ops.make_cfg(self.hidden_layer_config, self.w0, self.n_in_features, self.n_out_features, ww=self.ww)
+
+    def folded(self, latent_vec):
+        """(cfg, theta) of the 3-input network this one becomes for ONE latent vector in front of the coordinates (reference
+        src/evaluate.py:19-22 concatenates [latent | xyz]):  W_1 [latent | x] + b_1 = W_1[:, k:] x + (b_1 + W_1[:, :k] latent).
+        theta is a fresh flat buffer in the C-ABI layout of SIREN(3, 1, hidden); everything behind the first layer is copied."""
+        k = self.n_in_features - 3
+        lat = torch.as_tensor(latent_vec).reshape(-1)
+        if k < 1 or lat.numel() != k:
+            raise DudfError(f"latent vector of {lat.numel()} entries for a network with {self.n_in_features} inputs (3 + {max(k, 0)})")
+        flat = self.flat_parameters()
+        po, pk = self._padded_dims()[0]
+        w1 = flat[:po * pk].view(po, pk)
+        b1 = flat[po * pk:po * pk + po]
+        lat = lat.to(device=flat.device, dtype=flat.dtype)
+        theta = torch.cat([w1[:, k:].reshape(-1), b1 + w1[:, :k] @ lat, flat[po * pk + po:]])
+        return hip_ops.make_cfg(self.hidden_layer_config, self.w0, 3, self.n_out_features, ww=self.ww), theta
 
     # ---- forward --------------------------------------------------------------------------------------------
     def forward(self, x):
         """Same contract as reference src/model.py:116-135."""
+        if x.shape[-1] != 3 or self.n_in_features != 3:
+            raise DudfError(f"SIREN.forward: the HIP path takes 3-D points (got {x.shape[-1]} columns for n_in_features = "
+                            f"{self.n_in_features}); a latent-conditioned network is queried with evaluate(model, samples, latent_vec)")
         coords_org = x.clone().detach().requires_grad_(True)
         if coords_org.device.type != "cuda":
             raise DudfError("SIREN.forward: inputs must be on the GPU; this build has no CPU/PyTorch fallback path")

@@ -40,7 +40,11 @@ typedef struct dudf_net_cfg {
     int32_t n_in;            /* 3 */
     int32_t n_hidden_layers; /* L = len(hidden_layer_config), reference src/model.py:94-108 */
     int32_t hidden;          /* H, all hidden layers equal */
-    float   w0;              /* SineLayer frequency, reference src/model.py:25-30 (ww == w0) */
+    float   w0;              /* frequency of the FIRST SineLayer, reference src/model.py:25-30, :100 */
+    float   ww;              /* frequency of the other SineLayers (reference src/model.py:89-92, :103-106); 0 = the same as w0
+                                (round 4, ABI 0.5: the struct grew by this field).  sin(w0 (W_1 x + b_1)) = sin(ww (rho W_1 x + rho b_1))
+                                with rho = w0 / ww: the kernels run ONE frequency, ww, on a first layer scaled by rho when its
+                                A-operand forms are packed, and the first layer's gradient is scaled by rho on its way out */
 } dudf_net_cfg;
 
 /* number of floats in theta for this cfg (461 825 for 8x256) */

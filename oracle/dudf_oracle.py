@@ -27,6 +27,14 @@ batch-of-1 dimension (the reference carries one: (1,N,3)).
 import numpy as np
 
 
+def _wl(w0, l):
+    """Frequency of hidden layer l (0-based): `w0` is one number, or the pair (w0, ww) of reference src/model.py:89-106 —
+    the first SineLayer runs w0, every other one ww."""
+    if isinstance(w0, (tuple, list)):
+        return w0[0] if l == 0 else w0[1]
+    return w0
+
+
 # --------------------------------------------------------------------------
 # forward value  —  reference src/model.py:29-30 (SineLayer), :131-135 (SIREN.forward)
 # --------------------------------------------------------------------------
@@ -34,9 +42,9 @@ def forward(params, x, w0=30.0, xp=np):
     """y (N,), cache = {'s': [s_1..s_L], 'c': [c_1..c_L]} with s_l = sin(w0 z_l), c_l = cos(w0 z_l)."""
     h = x
     S, C = [], []
-    for W, b in params[:-1]:
+    for l, (W, b) in enumerate(params[:-1]):
         z = xp.matmul(h, W.T) + b            # nn.Linear
-        t = w0 * z                           # SineLayer: torch.sin(self.w0 * x)
+        t = _wl(w0, l) * z                   # SineLayer: torch.sin(self.w0 * x)
         s = xp.sin(t)
         S.append(s)
         C.append(xp.cos(t))
@@ -58,7 +66,7 @@ def input_gradient(params, cache, w0=30.0, xp=np):
     A, Q = [None] * L, [None] * L
     for l in range(L - 1, -1, -1):
         A[l] = a
-        q = w0 * cache["c"][l] * a
+        q = _wl(w0, l) * cache["c"][l] * a
         Q[l] = q
         a = xp.matmul(q, params[l][0])                  # a_{l-1} = W_l^T q_l
     return a, {"a": A, "q": Q}
@@ -79,13 +87,13 @@ def hessian(params, x, cache, rev, w0=30.0, xp=np):
         for l in range(L):
             zk = xp.matmul(hd, params[l][0].T)          # zdot_l = W_l hdot_{l-1}
             zd.append(zk)
-            hd = w0 * cache["c"][l] * zk               # hdot_l = w0 c_l zdot_l
+            hd = _wl(w0, l) * cache["c"][l] * zk       # hdot_l = w0 c_l zdot_l
         ad = 0.0 * cache["c"][-1]                        # reverse tangents: adot_L = 0
         adk = [None] * L
         for l in range(L - 1, -1, -1):
             adk[l] = ad
-            cd = -w0 * cache["s"][l] * zd[l]           # d c_l / d x_k
-            qd = w0 * (cd * rev["a"][l] + cache["c"][l] * ad)
+            cd = -_wl(w0, l) * cache["s"][l] * zd[l]   # d c_l / d x_k
+            qd = _wl(w0, l) * (cd * rev["a"][l] + cache["c"][l] * ad)
             ad = xp.matmul(qd, params[l][0])            # adot_{l-1} = W_l^T qdot_l
         cols.append(ad)                                 # (N,3) indexed by i: column k of H
         zd_all.append(zd)
@@ -255,9 +263,9 @@ def param_grad(params, x, cache, rev, ybar, gbar, w0=30.0, xp=np):
         for l in range(L):
             Ql = xp.matmul(Aprev, params[l][0].T)               # Q_l = W_l A_{l-1}
             dW[l] = dW[l] + xp.matmul(rev["q"][l].T, Aprev)      # q_l A_{l-1}^T summed over points
-            cbar[l] = w0 * rev["a"][l] * Ql
-            trace["e"][l] = w0 * s[l] * cbar[l]                  # = w0^2 s_l a_l Q_l
-            Aprev = w0 * c[l] * Ql
+            cbar[l] = _wl(w0, l) * rev["a"][l] * Ql
+            trace["e"][l] = _wl(w0, l) * s[l] * cbar[l]          # = w0^2 s_l a_l Q_l
+            Aprev = _wl(w0, l) * c[l] * Ql
             trace["A"][l] = Aprev
         dW[L] = dW[L] + Aprev.sum(0)[None, :]
     # (ii) adjoint of the forward sweep, runs backward in l
@@ -266,9 +274,9 @@ def param_grad(params, x, cache, rev, ybar, gbar, w0=30.0, xp=np):
     dW[L] = dW[L] + xp.matmul(ybar[None, :], s[L - 1])
     db[L] = db[L] + ybar.sum()[None]
     for l in range(L - 1, -1, -1):
-        zbar = w0 * c[l] * hbar
+        zbar = _wl(w0, l) * c[l] * hbar
         if cbar[l] is not None:
-            zbar = zbar - w0 * s[l] * cbar[l]
+            zbar = zbar - _wl(w0, l) * s[l] * cbar[l]
         trace["zbar"][l] = zbar
         hprev = x if l == 0 else s[l - 1]
         dW[l] = dW[l] + xp.matmul(zbar.T, hprev)
@@ -301,9 +309,9 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
         e[:, k] = 1.0
         hd[k][0] = e
         for l in range(L):
-            hd[k][l + 1] = w0 * c[l] * zd[k][l]
-            cd[k][l] = -w0 * s[l] * zd[k][l]
-            qd[k][l] = w0 * (cd[k][l] * a[l] + c[l] * ad[k][l])
+            hd[k][l + 1] = _wl(w0, l) * c[l] * zd[k][l]
+            cd[k][l] = -_wl(w0, l) * s[l] * zd[k][l]
+            qd[k][l] = _wl(w0, l) * (cd[k][l] * a[l] + c[l] * ad[k][l])
     # (i) adjoint of the reverse sweeps, forward in l
     Ap = gbar if gbar is not None else 0.0 * x
     Adp = [Hbar[:, :, k] for k in range(3)]
@@ -317,20 +325,20 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
         dW[l] = dW[l] + xp.matmul(rev["q"][l].T, Ap)
         for k in range(3):
             dW[l] = dW[l] + xp.matmul(qd[k][l].T, Adp[k])
-        chat = [w0 * a[l] * Qd[k] for k in range(3)]
-        Anew = w0 * c[l] * Q
-        cb = w0 * a[l] * Q
+        chat = [_wl(w0, l) * a[l] * Qd[k] for k in range(3)]
+        Anew = _wl(w0, l) * c[l] * Q
+        cb = _wl(w0, l) * a[l] * Q
         sb = 0.0 * Q
         for k in range(3):
-            Anew = Anew + w0 * cd[k][l] * Qd[k]
-            cb = cb + w0 * ad[k][l] * Qd[k]
-            sb = sb - w0 * zd[k][l] * chat[k]
-            zdbar_rev[k][l] = -w0 * s[l] * chat[k]
+            Anew = Anew + _wl(w0, l) * cd[k][l] * Qd[k]
+            cb = cb + _wl(w0, l) * ad[k][l] * Qd[k]
+            sb = sb - _wl(w0, l) * zd[k][l] * chat[k]
+            zdbar_rev[k][l] = -_wl(w0, l) * s[l] * chat[k]
         cbar_rev[l], sbar_rev[l] = cb, sb
-        Adp = [w0 * c[l] * Qd[k] for k in range(3)]
+        Adp = [_wl(w0, l) * c[l] * Qd[k] for k in range(3)]
         Ap = Anew
         tr["A"][l] = Ap
-        tr["E"][l] = w0 * c[l] * sb - w0 * s[l] * cb
+        tr["E"][l] = _wl(w0, l) * c[l] * sb - _wl(w0, l) * s[l] * cb
         for k in range(3):
             tr["Ad"][k][l] = Adp[k]
     dW[L] = dW[L] + Ap.sum(0)[None, :]
@@ -342,12 +350,12 @@ def param_grad_hessian(params, x, cache, rev, tang, ybar, gbar, Hbar, w0=30.0, x
     db[L] = db[L] + ybar.sum()[None]
     for l in range(L - 1, -1, -1):
         W = params[l][0]
-        zdbar = [zdbar_rev[k][l] + w0 * c[l] * hdbar[k] for k in range(3)]
+        zdbar = [zdbar_rev[k][l] + _wl(w0, l) * c[l] * hdbar[k] for k in range(3)]
         cb = cbar_rev[l]
         for k in range(3):
-            cb = cb + w0 * zd[k][l] * hdbar[k]
+            cb = cb + _wl(w0, l) * zd[k][l] * hdbar[k]
         sb = sbar_rev[l] + hbar
-        zbar = w0 * c[l] * sb - w0 * s[l] * cb
+        zbar = _wl(w0, l) * c[l] * sb - _wl(w0, l) * s[l] * cb
         tr["zbar"][l] = zbar
         for k in range(3):
             tr["zdbar"][k][l] = zdbar[k]
@@ -447,12 +455,12 @@ def third_derivatives(params, x, w0=30.0):
     h = np.zeros((N, 3, 4, 4, 4), dtype=x.dtype)
     h[:, :, 0, 0, 0] = x
     h[:, 0, 1, 0, 0] = 1.0; h[:, 1, 0, 1, 0] = 1.0; h[:, 2, 0, 0, 1] = 1.0
-    for W, b in params[:-1]:
+    for l, (W, b) in enumerate(params[:-1]):
         z = np.einsum("of,nfijk->noijk", W, h)
         z[:, :, 0, 0, 0] += b
-        a0 = w0 * z[:, :, 0, 0, 0]
+        a0 = _wl(w0, l) * z[:, :, 0, 0, 0]
         s, c = np.sin(a0)[..., None, None, None], np.cos(a0)[..., None, None, None]
-        u = w0 * z
+        u = _wl(w0, l) * z
         u[:, :, 0, 0, 0] = 0.0
         u2 = _poly_mul(u, u)
         u3 = _poly_mul(u2, u)

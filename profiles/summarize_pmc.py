@@ -25,7 +25,7 @@ NAMES = {"<256, 0, 3>": "sweep_fwd", "<256, 1, 1>": "sweep_rev", "<256, 2, 0>": 
 def kname(k):
     if "sweep_bf16_np_kernel" in k:
         k = k.replace("sweep_bf16_np_kernel", "sweep_bf16_kernel")      # the forward sweeps: build without packed fp32 ops
-    for f16 in ("sweep_f16_np_kernel", "sweep_f16_kernel"):             # the fp16x3 builds of the same sweeps (round 3)
+    for f16 in ("sweep_f16p_np_kernel", "sweep_f16p_kernel", "sweep_f16_np_kernel", "sweep_f16_kernel"):   # the fp16x3 builds of the same sweeps (round 3); f16p: 24-bit stash (round 4)
         if f16 in k:
             k = k.replace(f16, "sweep_bf16_kernel")
     for w in ("sweep_w16_kernel", "sweep_w_kernel"):                   # the 512-wide kernel: <SW, FL>
@@ -38,11 +38,12 @@ def kname(k):
     if "sweep_kernel" in k:
         sig = k.split("sweep_kernel")[1].split("(")[0]
         return NAMES.get(sig, "sweep" + sig) + "_f32"
-    for n in ("wgrad_hidden_f16p", "wgrad_hidden_bf16p", "wgrad_hidden_bf16", "wgrad_hidden", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel",
-              "pack_f16_kernel", "pack_bf16_kernel", "pack_kernel"):
+    for n in ("wgrad_hidden_f16p24", "wgrad_hidden_f16tr", "wgrad_hidden_f16p", "wgrad_hidden_bf16p", "wgrad_hidden_bf16", "wgrad_hidden",
+              "wgrad_small_p24", "wgrad_small", "loss_fwd", "loss_bwd", "adam_kernel", "prep_kernel", "pack_f16_kernel", "pack_bf16_kernel", "pack_kernel"):
         if n in k:
-            return (n.replace("_kernel", "").replace("wgrad_hidden_f16p", "wgrad_hidden").replace("wgrad_hidden_bf16p", "wgrad_hidden")
-                    .replace("wgrad_hidden_bf16", "wgrad_hidden"))
+            return (n.replace("_kernel", "").replace("wgrad_hidden_f16p24", "wgrad_hidden").replace("wgrad_hidden_f16tr", "wgrad_hidden")
+                    .replace("wgrad_hidden_f16p", "wgrad_hidden").replace("wgrad_hidden_bf16p", "wgrad_hidden")
+                    .replace("wgrad_hidden_bf16", "wgrad_hidden").replace("wgrad_small_p24", "wgrad_small"))
     return None
 
 
@@ -81,6 +82,12 @@ def main():
                           "read": m["hbm_read_bytes"], "write": m["hbm_write_bytes"],
                           "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "
                                     f"MI355X_MICROARCH.md; profiles/{tag}_pmc_summary.json"}
+        if "SQ_INSTS_MFMA" in m and k in traffic:         # bench.py checks its fp16x3 / bf16x6 label against this (x flops per instruction / algorithmic flops)
+            traffic[k]["mfma_insts_per_launch"] = m["SQ_INSTS_MFMA"]
+        if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:    # how much of what the kernel asks L2 for is served there
+            m["l2_hit_frac"] = m["TCC_HIT_sum"] / max(m["TCC_HIT_sum"] + m["TCC_MISS_sum"], 1.0)
+            if k in traffic:
+                traffic[k]["l2_hit_frac"] = round(m["l2_hit_frac"], 4)
         out[k] = {c: (round(x, 3) if isinstance(x, float) else x) for c, x in m.items()}
     here = os.path.dirname(os.path.abspath(__file__))
     json.dump(out, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)

@@ -299,6 +299,67 @@ def make_g10():
     np.savez_compressed(os.path.join(HERE, "g10_meshudf.npz"), **out)
 
 
+def make_g11():
+    """G11 (round 4): the two constructor arguments no shipped config uses but the reference's model accepts.
+      ww: SIREN(3, 1, hidden, w0=30, ww=15) — first SineLayer at w0, the others at ww (reference src/model.py:89-106): value,
+          df/dx, Hessian, the loss_s1 terms (Eikonal and full) and d(theta), fp64 and fp32 runs.  Hidden weights are drawn with
+          the bound the reference's `sine_init(ww)` uses.
+      latent: SIREN(3 + k, 1, hidden) queried through the reference's own `evaluate(model, samples, latent_vec, ...)`
+          (src/evaluate.py:5-36): values and gradients[..., k:]."""
+    out = {}
+    for tag, hid, pseed, n in (("tiny", [32, 32, 32], 5, 96), ("full", [256] * 8, 123, 300)):
+        P = synth.siren_params(hid, seed=pseed, w0=15.0, dtype=np.float64)       # sine_init(ww): hidden bound sqrt(6/fan)/ww
+        batch = synth.training_batch(n, seed=pseed + 1, dtype=np.float64)
+        out[f"ww_{tag}_hidden"] = np.array(hid); out[f"ww_{tag}_param_seed"] = pseed; out[f"ww_{tag}_n"] = n
+        for dt, dn in ((torch.float64, "f64"), (torch.float32, "f32")):
+            model = SIREN(3, 1, hid, w0=30, ww=15).double()
+            model.load_state_dict({f"net.{i}.0.{k}": torch.from_numpy(np.asarray(a, dtype=np.float64))
+                                   for i, (w, b) in enumerate(P) for k, a in (("weight", w), ("bias", b))})
+            model = model.to(dt)
+            x, nrm, sdf = [torch.from_numpy(a.astype(np.float32).astype(np.float64)).to(dt)[None] for a in batch]
+            mo = model(x)
+            xin, y = mo["model_in"], mo["model_out"]
+            out[f"ww_{tag}_{dn}_y"] = y.detach().double().numpy()[0, :, 0]
+            out[f"ww_{tag}_{dn}_g"] = gradient(y, xin).detach().double().numpy()[0]
+            out[f"ww_{tag}_{dn}_H"] = hessian(y, xin).detach().double().numpy()[0]
+            for name, w in (("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])):
+                model.zero_grad()
+                terms = loss_s1(model, x, {"normals": nrm, "sdf": sdf}, w, 100)
+                total = torch.zeros((1, 1), dtype=dt)
+                for v in terms.values():
+                    total = total + v
+                total.backward()
+                out[f"ww_{tag}_{dn}_{name}_terms"] = np.array([float(v) for v in terms.values()])
+                gr = flat_grads(model)
+                if tag == "tiny":
+                    out[f"ww_{tag}_{dn}_{name}_dtheta"] = gr
+                else:                                        # 461 825 parameters: every 97th + the norms
+                    out[f"ww_{tag}_{dn}_{name}_dtheta_sample"] = gr[::97]
+                    out[f"ww_{tag}_{dn}_{name}_dtheta_norm"] = np.array([np.linalg.norm(gr), np.abs(gr).max()])
+    # latent vector: k extra input features in FRONT of the coordinates (src/evaluate.py:21-22)
+    k = 5
+    for tag, hid, pseed, n in (("tiny", [32, 32, 32], 9, 80), ("full", [256] * 8, 321, 200)):
+        P = synth.siren_params(hid, seed=pseed, n_in=3 + k, dtype=np.float64)
+        lat = (synth.uniform01(pseed, 77, 0, k) * 2.0 - 1.0)[None, :]
+        xs = (synth.uniform01(pseed, 78, 0, 3 * n).reshape(n, 3) * 2.0 - 1.0).astype(np.float32)
+        out[f"lat_{tag}_hidden"] = np.array(hid); out[f"lat_{tag}_param_seed"] = pseed; out[f"lat_{tag}_k"] = k
+        out[f"lat_{tag}_latent"] = lat; out[f"lat_{tag}_x"] = xs
+        for dt, dn in ((torch.float64, "f64"), (torch.float32, "f32")):
+            model = SIREN(3 + k, 1, hid, w0=30).double()
+            model.load_state_dict({f"net.{i}.0.{kk}": torch.from_numpy(np.asarray(a, dtype=np.float64))
+                                   for i, (w, b) in enumerate(P) for kk, a in (("weight", w), ("bias", b))})
+            model = model.to(dt)
+            # (no `hessians=`: the reference's hessian() differentiates the first three INPUT features — latent components here —
+            #  and its evaluate() then fails with a shape error, src/diff_operators.py:187-193, src/evaluate.py:32)
+            grads = np.zeros((n, 3))
+            samples = torch.from_numpy(xs.astype(np.float64)).to(dt)
+            vals = evaluate(model, samples, latent_vec=torch.from_numpy(lat).to(dt), max_batch=64, device=torch.device("cpu"),
+                            gradients=grads)
+            out[f"lat_{tag}_{dn}_y"] = vals[:, 0]; out[f"lat_{tag}_{dn}_g"] = grads
+    np.savez_compressed(os.path.join(HERE, "g11_ww_latent.npz"), **out)
+    print("g11_ww_latent.npz:", len(out), "arrays")
+
+
 def main():
     # ---- G1: tiny net, everything stored --------------------------------------------------
     out = {}
@@ -424,5 +485,7 @@ if __name__ == "__main__":
         make_g9()
     elif sys.argv[1:] == ["g10"]:
         make_g10()
+    elif sys.argv[1:] == ["g11"]:
+        make_g11()
     else:
         main()

@@ -186,3 +186,46 @@ def test_ray_marching_oracle_against_reference(golden_dir, tag):
     t1 = G[f"{tag}_t0_traced"].copy()
     R.grad_descent(P, t1, hits_ref, "tanh", float(G[f"{tag}_alpha"]), int(G[f"{tag}_gd_steps"]))
     assert np.abs(t1 - G[f"{tag}_t0_descended"]).max() < 1e-4
+
+
+# ---- g11: ww != w0 and a latent vector in front of the coordinates (reference src/model.py:89-106, src/evaluate.py:19-22) -------
+def _g11(golden_dir):
+    return np.load(os.path.join(golden_dir, "g11_ww_latent.npz"))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_oracle_ww_against_the_reference(golden_dir, tag):
+    """The oracle with the frequency pair (w0, ww) = (30, 15) against the reference's own SIREN(3, 1, hidden, w0=30, ww=15)."""
+    G = _g11(golden_dir)
+    hid = list(G[f"ww_{tag}_hidden"]); n = int(G[f"ww_{tag}_n"]); seed = int(G[f"ww_{tag}_param_seed"])
+    P = synth.siren_params(hid, seed=seed, w0=15.0, dtype=np.float64)
+    x, nrm, sdf = [a.astype(np.float32).astype(np.float64) for a in synth.training_batch(n, seed=seed + 1, dtype=np.float64)]
+    W = (30.0, 15.0)
+    y, g, H = O.query(P, x, w0=W, want_grad=True, want_hess=True)
+    assert rel(y, G[f"ww_{tag}_f64_y"]) < 1e-11 and rel(g, G[f"ww_{tag}_f64_g"]) < 1e-11 and rel(H, G[f"ww_{tag}_f64_H"]) < 1e-10
+    for name, w in (("s1eik", [1e4, 1e4, 0.0, 1e3]), ("s1full", [1e4, 1e4, 1e4, 1e3])):
+        terms, grads, _ = O.loss_and_grad("s1", P, x, nrm, sdf, w, 100.0, w0=W)
+        assert rel(np.array([float(v) for v in terms.values()]), G[f"ww_{tag}_f64_{name}_terms"]) < 1e-11
+        flat = np.concatenate([np.concatenate([a.reshape(-1), b.reshape(-1)]) for a, b in grads])
+        if tag == "tiny":
+            assert rel(flat, G[f"ww_{tag}_f64_{name}_dtheta"]) < 1e-9
+        else:
+            assert rel(flat[::97], G[f"ww_{tag}_f64_{name}_dtheta_sample"]) < 1e-9
+            assert abs(np.linalg.norm(flat) / G[f"ww_{tag}_f64_{name}_dtheta_norm"][0] - 1) < 1e-10
+    # the C ABI runs ONE frequency on a first layer scaled by rho = w0 / ww: the same function, restated here
+    P2 = [(P[0][0] * 2.0, P[0][1] * 2.0)] + list(P[1:])
+    y2, g2, _ = O.query(P2, x, w0=15.0)
+    assert rel(y2, y) < 1e-12 and rel(g2, g) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_latent_vector_folds_into_the_first_bias(golden_dir, tag):
+    """evaluate(model, samples, latent_vec) of the reference = the 3-input network with b_1 + W_1[:, :k] latent (what
+    diffudf_amd.model.SIREN.folded builds), checked with the oracle against the reference's values and gradients[..., k:]."""
+    G = _g11(golden_dir)
+    hid = list(G[f"lat_{tag}_hidden"]); k = int(G[f"lat_{tag}_k"]); seed = int(G[f"lat_{tag}_param_seed"])
+    P = synth.siren_params(hid, seed=seed, n_in=3 + k, dtype=np.float64)
+    lat = G[f"lat_{tag}_latent"][0]; x = G[f"lat_{tag}_x"].astype(np.float64)
+    P3 = [(P[0][0][:, k:], P[0][1] + P[0][0][:, :k] @ lat)] + list(P[1:])
+    y, g, _ = O.query(P3, x)
+    assert rel(y, G[f"lat_{tag}_f64_y"]) < 1e-11 and rel(g, G[f"lat_{tag}_f64_g"]) < 1e-11
