@@ -83,6 +83,7 @@ class _FusedLoss(torch.autograd.Function):
             if ok is not None:                         # a wrong layout hint must not train silently
                 terms = torch.where(ok, terms, torch.full_like(terms, float("nan")))
         ctx.model, ctx.mode, ctx.ws, ctx.stats, ctx.n_hess = model, mode, ws, stats, n_hess
+        ctx.ok = ok
         ctx.args = (x, normals, sdf, list(weights), alpha, n_global)
         ctx.stamp = ws.generation
         return terms
@@ -96,11 +97,18 @@ class _FusedLoss(torch.autograd.Function):
         x, normals, sdf, weights, alpha, n_global = ctx.args
         cot = torch.zeros(4, dtype=torch.float32, device=x.device)
         cot[:grad_terms.numel()] = grad_terms.float()
+        if ctx.ok is not None:
+            # a wrong gt['n_on_surface'] made the forward terms NaN; the batch is then partitioned wrongly for the backward
+            # as well (Hessian quads on the wrong points): the gradient must be NaN too, not finite garbage that Adam applies
+            cot = torch.where(ctx.ok, cot, torch.full_like(cot, float("nan")))
         theta = model.flat_parameters()
         # A loop that keeps every p.grad as a view of ONE flat buffer (train.py::_zero_flat_grad) gets the gradient written —
         # accumulated, as autograd would — straight into it: no temporary, none of the 18 per-parameter add kernels of
         # AccumulateGrad.  Anything else (fresh .grad, foreign tensors): the gradients are returned to autograd as usual.
-        flat = getattr(model, "_dudf_flat_grad", None)
+        # OPT-IN (`model.dudf_direct_grad = True`, set by train.py next to its flat buffer): the direct path returns None for
+        # every parameter, so torch.autograd.grad(loss, params), backward(inputs=...) and parameter hooks would see no
+        # gradient — a caller that uses those leaves the flag off and gets ordinary autograd semantics.
+        flat = getattr(model, "_dudf_flat_grad", None) if getattr(model, "dudf_direct_grad", False) else None
         sig = getattr(model, "_dudf_flat_grad_sig", None)
         if flat is not None and sig is not None and flat.device == theta.device and flat.numel() >= theta.numel():
             params = list(model.parameters())

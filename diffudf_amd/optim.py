@@ -9,7 +9,8 @@ flat gradient buffer (what `train.py::_zero_flat_grad` sets up), one `dudf_adam_
 replays torch's CUDA Adam operation by operation (csrc/dudf_misc.hip; tests/test_api_gpu.py holds a 10-step trajectory to
 2e-7), instead of torch's six foreach launches over 18 tensors and their host-side bookkeeping (0.3 ms of Python a step,
 which is what the stage-2 epochs of the reference recipe are bound by).  The fast path's moments are flat tensors of its
-own: `state_dict()` then carries no per-parameter state (the reference never saves the optimizer).
+own; `state_dict()` / `load_state_dict()` convert them to and from torch.optim.Adam's per-parameter layout (`step`,
+`exp_avg`, `exp_avg_sq`), so a checkpoint written by either implementation resumes in the other.
 """
 import torch
 
@@ -63,3 +64,35 @@ class Adam(torch.optim.Adam):
         self._t += 1
         hip_ops.adam_step(theta, dtheta, self._m, self._v, self._t, g["lr"], g["betas"][0], g["betas"][1], g["eps"])
         return None
+
+    # ---- checkpoints: torch.optim.Adam's per-parameter state <-> the flat moments ------------------------------------------
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._m is not None and self._t > 0 and not self._fell_back and self._model is not None:
+            ms, vs = self._model.split_flat(self._m), self._model.split_flat(self._v)
+            sd["state"] = {i: {"step": torch.tensor(float(self._t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+                           for i, (m, v) in enumerate(zip(ms, vs))}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        st = state_dict.get("state", {})
+        if not st:
+            return
+        if self._model is None:
+            return                                      # plain torch.optim.Adam behaviour
+        if self._t > 0 and self._fell_back:
+            return                                      # already on torch's own step(): its state was just loaded
+        theta = self._model.flat_parameters()
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        steps = set()
+        params = list(self._model.parameters())
+        if len(st) != len(params):
+            raise ValueError(f"optimizer state for {len(st)} parameters, the model has {len(params)}")
+        for (idx, s), mv, vv in zip(sorted(st.items()), self._model.split_flat(m), self._model.split_flat(v)):
+            mv.copy_(s["exp_avg"].to(theta.device)); vv.copy_(s["exp_avg_sq"].to(theta.device))
+            steps.add(int(float(s["step"])))
+        if len(steps) != 1:
+            raise ValueError("diffudf_amd.optim.Adam: per-parameter step counts differ; the flat update has one")
+        self._m, self._v, self._t = m, v, steps.pop()
+        self.state.clear()                              # the flat moments are the state from here on (the fast path owns it)

@@ -66,6 +66,9 @@ def _zero_flat_grad(model):
         flat = model._dudf_flat_grad = torch.zeros(theta.numel() + 4, dtype=torch.float32, device=theta.device)
         views = model._dudf_flat_grad_views = model.split_flat(flat[:theta.numel()])
         model._dudf_flat_grad_sig = [(v.data_ptr(), v.stride()) for v in views]
+        # this loop only ever calls train_loss.backward(): the fused loss may write d(theta) straight into the flat buffer
+        # (diffudf_amd/loss_functions.py::_FusedLoss.backward; torch.autograd.grad / hooks would need the flag off)
+        model.dudf_direct_grad = True
     else:
         flat.zero_()
     for p, v, (ptr, _) in zip(model.parameters(), views, model._dudf_flat_grad_sig):
@@ -132,6 +135,10 @@ def _train(dataset, model, device, config, schedule):
             for it, v in zip(names, vals):
                 running_loss[it] = running_loss.get(it, 0.0) + v
             writer.add_scalar("train_loss", sum(vals), epoch)
+        bad = [it for it, l in running_loss.items() if l != l]
+        if bad:                                        # NaN terms: a wrong gt['n_on_surface'] hint, or a diverged run — never train on
+            raise RuntimeError(f"epoch {epoch}: loss term(s) {bad} are NaN; the parameters have been updated with NaN gradients since "
+                               "(the bookkeeping runs one epoch late) — restart from the last checkpoint")
         for it, l in running_loss.items():
             if it not in losses:
                 losses[it] = [0.] * epochs
