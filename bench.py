@@ -236,7 +236,7 @@ SPLIT_BIT = {"sweep_fwd": 0, "sweep_rev": 1, "sweep_adj_fwd": 2, "sweep_adj_rev"
 def same_build(meta):
     """Were the PMC files collected on the stash mode / split this run uses?  (a label check against counters of another
     configuration would be meaningless; the A/B switches change what runs)"""
-    return not any(os.environ.get(v) for v in ("DUDF_SPLIT", "DUDF_SPLIT_SWEEPS", "DUDF_SWEEP", "DUDF_WGRAD", "DUDF_STASH"))
+    return not any(os.environ.get(v) for v in ("DUDF_SPLIT", "DUDF_SPLIT_QUADS", "DUDF_SWEEP", "DUDF_WGRAD", "DUDF_WGRAD_TR", "DUDF_STASH"))
 
 
 def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):

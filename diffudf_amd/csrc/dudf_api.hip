@@ -52,13 +52,12 @@ bool dudf_split_fp16() {
     static const bool on = [] { const char* e = getenv("DUDF_SPLIT"); return !(e && e[0] == 'b'); }();
     return on;
 }
-// which plain-column sweeps run fp16x3: DUDF_SPLIT_SWEEPS = bit mask (bit 0 forward .. bit 3 adjoint reverse; A/B testing)
-// bit 5: the 512-wide Hessian-quad / jet sweeps as well (DUDF_SPLIT_QUADS=0: bf16x6)
+// which sweeps run fp16x3: bits 0-3 the plain columns' four sweeps (all or none: the adjoint reverse sweep's column scale
+// comes from the fp16x3 adjoint forward sweep), bit 5 the Hessian quads / jets as well (DUDF_SPLIT_QUADS=0: bf16x6)
 int dudf_split_mask() {
     static const int m = [] {
-        const char* e = getenv("DUDF_SPLIT_SWEEPS");
         const char* q = getenv("DUDF_SPLIT_QUADS");
-        return (e ? atoi(e) & 15 : 15) | ((q && q[0] == '0') ? 0 : 32);
+        return 15 | ((q && q[0] == '0') ? 0 : 32);
     }();
     return dudf_split_fp16() ? m : 0;
 }
@@ -81,10 +80,9 @@ bool dudf_stash_p24_enabled(int H, int L) {
         const char* e = getenv("DUDF_STASH");
         const bool on = e ? strstr(e, "p24") != nullptr : DUDF_STASH_DEFAULT_P24;
         if (!on) return false;
-        const char* w = getenv("DUDF_WGRAD"); const char* v = getenv("DUDF_WGRAD_VAR");
+        const char* w = getenv("DUDF_WGRAD");
         if (w && w[0]) return false;                                        // f32 / bf16w weight-gradient kernels read fp32 rows
-        if (v && (atoi(v) & 15) != 9) return false;
-        return use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47 && !getenv("DUDF_LATE_FORCE");
+        return use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47;
     }();
     return want && H == 256 && L >= 2 && L <= 32;
 }
@@ -120,8 +118,6 @@ SweepArgs make_sweep_args(const DudfLayout& lo, const float* theta, float* ws) {
     a.store_s = 0; a.store_c = 0; a.train = 0; a.have_e = 1;
     a.tile0 = 0; a.ntiles = 0; a.hess = 0;
     a.p24 = lo.p24;
-    static const int prio = [] { const char* e = getenv("DUDF_SWEEP_PRIO"); return e ? atoi(e) : 0; }();
-    a.prio = prio;
     return a;
 }
 

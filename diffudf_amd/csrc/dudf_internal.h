@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //
 // workspace:
 //   w1b    [H][4]      = rho [W_1 | b_1]    A-operand of the first layer (bias folded in as k=3); rho = w0 / ww (1 unless ww != w0)
-//   b1s    [H]         = rho b_1
+//   b1s    [L][H]      = rho b_1 | b_2 | .. | b_L: the hidden layers' biases, contiguous per layer (the forward tails index it by layer)
 //   w1t16  [16][H]     rows 0..2 = rho W_1^T, rest 0: A-operand of the last reverse step (df/dx)
 //   wt     [L-1][H][H] W_l^T for l=2..L     A-operand of the reverse sweeps (f32 kernel)
 //   wimg   bf16x3 images of W_l, then of W_l^T, in A-fragment order (dudf_sweep_bf16.hip)
@@ -116,12 +116,9 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     // 256-byte segment of a stash row is then exactly two 128-byte lines.  (Round 3 first put two small arrays of 64 + 128 bytes
     // in front of the stash: every segment straddled three lines, and FETCH_SIZE / WRITE_SIZE of all four sweeps read 9-12 %
     // above the algorithmic bytes until this was noticed — profiles/r03_a, r03_b against r02_c.)
-    // DUDF_STASH_SKEW=<n> (experiment): n * 256 bytes of padding behind every array, so that the stash arrays a sweep streams
-    // together do not sit at identical offsets modulo the HBM channel / bank interleave
-    static const int64_t skew = [] { const char* e = getenv("DUDF_STASH_SKEW"); return e ? (int64_t)atoi(e) * 64 : (int64_t)0; }();
-    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64 + skew; return r; };
+    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64; return r; };
     lo->ws_w1b = take(4 * (int64_t)H);
-    lo->ws_b1s = take((int64_t)H);                                 // rho b_1, contiguous (the forward tails' bias of the first layer)
+    lo->ws_b1s = take((int64_t)L * H);                             // rho b_1 | b_2 .. b_L (the forward tails' biases, one row per layer)
     lo->ws_w1t16 = take(16 * (int64_t)H);
     lo->ws_wt = take((int64_t)(L - 1) * H * H);
     lo->ws_wimg = take((int64_t)(L - 1) * H * H * 3);      // bf16x3 images of W_l and W_l^T: 2 x 6 bytes per weight
@@ -163,7 +160,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
 struct SweepArgs {
-    const float* theta; const float* w1b; const float* b1s; const float* w1t16; const float* wt;   // b1s: rho b_1 (first-layer bias as packed)
+    const float* theta; const float* w1b; const float* b1s; const float* w1t16; const float* wt;   // b1s: [L][H] biases as packed (row 0 = rho b_1)
     const char* wimg_f; const char* wimg_t;   // bf16x3 weight images (forward / transposed), dudf_sweep_bf16.hip
     const char* wimg16_f; const char* wimg16_t;   // fp16 hi/lo weight images, scaled by 2^k_l per matrix
     const float* wsc;         // [2][L-1]: 2^-k_l | 2^k_l
@@ -184,7 +181,6 @@ struct SweepArgs {
     int L; float w0;
     int store_s, store_c, train;   // what the sweep has to leave behind
     int have_e;                    // reverse adjoint sweep: e_l was produced by SWEEP_ADJ_FWD
-    int prio;                      // bf16 sweeps: static priority for waves 0-3 of a workgroup (stagger of the SIMD partners)
     int p24;                       // S, Q, R, E, A, Z are 24-bit tile-major arrays (DudfLayout::p24)
 };
 

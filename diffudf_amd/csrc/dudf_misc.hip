@@ -19,6 +19,10 @@ __global__ void pack_kernel(const float* __restrict__ theta, float* __restrict__
         w1b[gid] = rho * (k < 3 ? theta[f * 3 + k] : theta[3 * H + f]);
         if (k == 3) b1s[f] = rho * theta[3 * H + f];
     }
+    if (gid >= H && gid < (int64_t)L * H) {             // b1s rows 1 .. L-1 = b_2 .. b_L
+        const int layer = (int)(gid / H), f = (int)(gid % H);
+        b1s[gid] = theta[off_hid + (int64_t)(layer - 1) * hid_stride + (int64_t)H * H + f];
+    }
     if (gid < 16 * (int64_t)H) {                        // w1t16[r][f] = r<3 ? W_1[f][r] : 0
         const int r = (int)(gid / H), f = (int)(gid % H);
         w1t16[gid] = r < 3 ? rho * theta[f * 3 + r] : 0.f;
@@ -639,6 +643,7 @@ int dudf_launch_pack(const DudfLayout& lo, const float* theta, float* ws, hipStr
     DudfProfScope prof(PROF_PACK, st);
     int64_t n = (int64_t)(lo.L - 1) * lo.H * lo.H;
     if (n < 16 * (int64_t)lo.H) n = 16 * (int64_t)lo.H;
+    if (n < (int64_t)lo.L * lo.H) n = (int64_t)lo.L * lo.H;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, ws + lo.ws_w1b, ws + lo.ws_b1s,
                        ws + lo.ws_w1t16, ws + lo.ws_wt, lo.H, lo.L, lo.off_hid, lo.hid_stride, lo.rho);
     return (int)hipGetLastError();

@@ -33,30 +33,15 @@
 #include "dudf_sweep_common.h"
 #include <type_traits>
 
-// tuning knobs of sweep_tile_b (A/B builds through tools/build_dbg.sh; the expressions are evaluated inside the template)
-#ifndef DUDF_TP
-#define DUDF_TP (SP ? 2 : 1)                 // tiles per MFMA trip (chains interleaved)
-#endif
-#ifndef DUDF_AD
-#define DUDF_AD 4
-#endif
-#ifndef DUDF_HI_DMA
-#define DUDF_HI_DMA 0                        // partial passes: the idle half issues the DMA pieces (measured: no gain)
-#endif
+// Variants that were built, measured and NOT kept (tails of a pair half a step apart, one operand set for the fp16x3 adjoint
+// forward sweep, one tile at a time, DMA pieces issued by the idle half of a partial pass, static / per-phase wave priorities,
+// other fragment prefetch distances and feed / tail slots) are no longer in this file: DESIGN.md Appendix A has their numbers,
+// `git log -- diffudf_amd/csrc/dudf_sweep_bf16.hip` (round 3) their code.
 #ifndef DUDF_FWD_F16_KERNEL
 #define DUDF_FWD_F16_KERNEL sweep_f16_np_kernel   // A/B: sweep_f16_kernel = the build WITH packed fp32 instructions
 #endif
 #ifndef DUDF_OCT
 #define DUDF_OCT 1                           // a pass with a single 16-column group is shared by all eight waves (sweep_tile_oct)
-#endif
-#ifndef DUDF_TSPLIT
-#define DUDF_TSPLIT 0
-#endif
-#ifndef DUDF_ONESET
-#define DUDF_ONESET 0
-#endif
-#ifndef DUDF_TAILSEQ
-#define DUDF_TAILSEQ 0
 #endif
 #ifndef DUDF_W_RELAY_NT
 #define DUDF_W_RELAY_NT 0                    // 512-wide kernel: 1 = non-temporal stores for the relay array as well (rounds 2-3)
@@ -356,7 +341,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // layer whose tail feeds matrix j (j == nhid: the last one, feeding the output stage), 0-based
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {   // forward sweep: b_{layer+1}
-        return layer == 0 ? a.b1s : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;   // (b1s: rho b_1 as packed)
+        return a.b1s + (size_t)layer * H;              // [L][H] biases as packed (row 0 = rho b_1)
     };
     auto stash_base = [&](int layer, int T) -> int64_t {              // wave-uniform, and told so: SGPR base + lane offset
         const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
@@ -397,9 +382,6 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             e1 = epilogue<SW, FL, false, P24 != 0>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (kColScale) {            // accumulators -> true values first (2^-k_j / sb of the matrix that made them)
             e0 = epilogue<SW, FL, kTrackE, P24 != 0>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
-#if DUDF_TAILSEQ
-            if constexpr (BS == SWEEP_ADJ_FWD) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the pair's temporaries do not fit
-#endif
             e1 = epilogue<SW, FL, kTrackE, P24 != 0>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else {
             e0 = epilogue<SW, FL, false, P24 != 0>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
@@ -429,9 +411,8 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // the other half, which idled at the barrier, takes them (-0.9 % on the step; the reverse assignment: no gain).
     // A partial pass with at most four active waves (the last pass of a workgroup's share: at 100 000 points a single wave in
     // 112 workgroups) leaves waves 4-7 idle: they take all the pieces then, the active waves none.
-    const bool hi_dma = DUDF_HI_DMA && nact <= NWB / 2;
     auto dma2 = [&](const char* src, unsigned dst) {
-        if (hi_dma ? wave >= NWB / 2 : wave < NWB / 2) {
+        if (wave < NWB / 2) {
             const int w = wave & (NWB / 2 - 1);
             dma_issue<H, SP>(src, dst, voff, w); dma_issue<H, SP>(src, dst, voff, w + NWB / 2);
         }
@@ -475,7 +456,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     // loaded right behind the DMA: a full step ahead); the quad variants have a third operand array and no registers
     // for that — one set, refilled right after the tail that consumed it (about 0.8 step ahead).
     // (the fp16x3 adjoint forward sweep — two loads, two stores and the column scales — fits its registers with one set only)
-    constexpr bool kOneSet = HS || (SP != 0 && BS == SWEEP_ADJ_FWD && DUDF_ONESET);
+    constexpr bool kOneSet = HS;
     TailOps ops_cur, ops_n1;
     u32x4 bp[NPC];                                     // B operand of the current step: bf16 h | m | l, or fp16 hi | lo
     auto split = [&](const f32x4 e0, const f32x4 e1, u32x4 (&o)[NPC]) {
@@ -524,17 +505,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     #ifdef DUDF_LATE_FORCE                                 // tests/isa_contract.py: one half's program order at a time, branch-free
     const bool late = kLateOk && DUDF_LATE_FORCE;
 #else
-    const bool late = kLateOk && __builtin_amdgcn_readfirstlane((int)((a.prio & 4) == 0 && wave >= NWB / 2)) != 0;   // DUDF_SWEEP_PRIO=4: off (A/B)
+    const bool late = kLateOk && __builtin_amdgcn_readfirstlane((int)(wave >= NWB / 2)) != 0;
 #endif
     // feed slot: after which tile's MFMAs a wave issues its DMA pieces and operand loads (-1: at the top of the step);
     // tail slot: after which tile's MFMAs it runs the tail of the next step.  A = waves 0-3, B = waves 4-7 (when `late`).
-#ifndef DUDF_FA
-#define DUDF_FA -1
-#define DUDF_TA 0
-#define DUDF_FB (BS == SWEEP_FWD ? 15 : 7)
-#define DUDF_TB 15
-#endif
-    constexpr int FA = DUDF_FA, TA = DUDF_TA * (G::NT - 1) / 15, FB = DUDF_FB < 0 ? -1 : DUDF_FB * (G::NT - 1) / 15, TB = DUDF_TB * (G::NT - 1) / 15;
+    constexpr int FA = -1, TA = 0, FB = (BS == SWEEP_FWD ? 15 : 7) * (G::NT - 1) / 15, TB = G::NT - 1;
     for (int j = 0; j < nhid; ++j) {
         const int lin = in_layer(j), lnx = in_layer(j + 1);
 #pragma unroll
@@ -560,7 +535,6 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                 if constexpr (!kOneSet) load_after_next(ops_n1);          // one full step ahead
             };
             u32x4 nb[NPC];
-            f32x4 te0 = {0, 0, 0, 0};
             // fp16x3: the half that does not multiply first runs its tail at the very top of the step, in front of its DMA
             // pieces (fetched two steps ahead: no hurry) and of its first LDS fragment: the step is (tail of one half beside the
             // MFMAs of the other) twice, and neither tail should wait for anything
@@ -580,19 +554,16 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             // A fragments travel two tiles (12 MFMAs, ~190 cycles) ahead of their use: with both waves of a SIMD and the
             // chunk DMA on the LDS, one tile of distance does not cover the read latency
             // (fp16x3: FOUR tiles = 12 MFMAs: a tile is only three MFMAs long)
-            constexpr int AD = (SP && BS == SWEEP_FWD) ? DUDF_AD : 2;   // (the other fp16x3 sweeps need the registers: two tiles)
+            constexpr int AD = (SP && BS == SWEEP_FWD) ? 4 : 2;   // (the other fp16x3 sweeps need the registers: two tiles)
             u32x4 an[AD][NPC];
 #pragma unroll
             for (int T = 0; T < AD; ++T)
 #pragma unroll
                 for (int pc = 0; pc < NPC; ++pc) an[T][pc] = frag(T, pc);
-#ifdef DUDF_MPRIO
-            __builtin_amdgcn_s_setprio(1);                              // the wave that multiplies wins the issue arbitration
-#endif
             // TP tiles per trip, their MFMA chains interleaved: a tile's products accumulate into ONE register quad, and a
             // wave that issues them back to back waits out each MFMA's latency (fp16x3: three-instruction chains — alone on
             // the pipe a wave reached one MFMA per ~34 cycles instead of 16)
-            constexpr int TP = DUDF_TP;
+            constexpr int TP = SP ? 2 : 1;
 #pragma unroll
             for (int T = 0; T < G::NT; T += TP) {
                 u32x4 af[TP][NPC];
@@ -643,44 +614,16 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
                     DUDF_STAMP(7);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // DUDF_TSPLIT (fp16x3, stash-bound sweeps): the pair's two tiles run their tails half a step apart — loads waited
-                // for, stores issued in two smaller bursts instead of one
-                constexpr bool kTSplit = DUDF_TSPLIT && kColScale && !kOneSet;
-                constexpr int TA1 = TA, TA2 = TA + G::NT / 2, TB1 = TB - G::NT / 2, TB2 = TB;
-                if constexpr (kTSplit) {
-                    if (kb + 1 < G::NKB && ((TA1 >= T && TA1 <= Tl && !late) || (TB1 >= T && TB1 <= Tl && late))) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("" : "+v"(ops_cur.o1a), "+v"(ops_cur.o2a));
-                        te0 = epilogue<SW, FL, kTrackE, P24 != 0>(a, prev[2 * kb + 2] * unscale, ops_cur.o1a, ops_cur.o2a, ops_cur.o3a, stash_base(lin, 2 * kb + 2), vl, isv, tmax);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (kb + 1 < G::NKB && ((TA2 >= T && TA2 <= Tl && !late) || (TB2 >= T && TB2 <= Tl && late))) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("" : "+v"(ops_cur.o1b), "+v"(ops_cur.o2b));
-                        const f32x4 te1 = epilogue<SW, FL, kTrackE, P24 != 0>(a, prev[2 * kb + 3] * unscale, ops_cur.o1b, ops_cur.o2b, ops_cur.o3b, stash_base(lin, 2 * kb + 3), vl, isv, tmax);
-                        split(te0, te1, nb);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if (!kTSplit && kb + 1 < G::NKB && ((TA >= T && TA <= Tl && !late && !kTailTop) || (TB >= T && TB <= Tl && late))) {   // the next step's B operand
+                if (kb + 1 < G::NKB && ((TA >= T && TA <= Tl && !late && !kTailTop) || (TB >= T && TB <= Tl && late))) {   // the next step's B operand
                     if (T != 0) __builtin_amdgcn_sched_barrier(0);
                     DUDF_STAMP(2);
-#ifdef DUDF_MPRIO
-                    __builtin_amdgcn_s_setprio(0);
-#endif
                     f32x4 e0, e1;
                     run_tail(lin, kb + 1, prev[2 * kb + 2], prev[2 * kb + 3], ops_cur, e0, e1);
                     split(e0, e1, nb);
                     if constexpr (kOneSet) load_after_next(ops_cur);
-#ifdef DUDF_MPRIO
-                    if (Tl + 1 < G::NT) __builtin_amdgcn_s_setprio(1);
-#endif
                     DUDF_STAMP(3);
                 }
             }
-#ifdef DUDF_MPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             if (kb + 1 == G::NKB) {                                     // layer done: first tail of the next one
                 if constexpr (kColScale) {
                     // this matrix consumed the operand scaled by sb: its accumulators are 2^k_j sb x the true values
@@ -986,14 +929,10 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, 
         const float bq = (DUDF_QT && SW == SWEEP_FWD) ? a.w0 * 0.636619772367581343f : 1.f;
         for (int i = threadIdx.x; i < a.L * H; i += 64 * NWB) {
             const int layer = i / H, f = i - layer * H;
-            lb[i] = bq * (layer == 0 ? a.b1s[f] : a.theta[a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H + f]);
+            lb[i] = bq * a.b1s[i];                        // [L][H] biases as packed (row 0 = rho b_1)
+            (void)layer; (void)f;
         }
     }
-    // the two waves of a SIMD (w, w + 4) leave every k-block barrier in lockstep: tails coincide, MFMA streams collide.
-    // A static priority for one half lets it run its tail first at every contended issue slot; the partner falls one tail
-    // behind and from then on overlaps its tail with the other's MFMAs (MI355X_MICROARCH.md, "two waves per SIMD", 4 and 9)
-    if (a.prio == 1) { if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(1); }
-    else if (a.prio == 2) { if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1); }
     // balanced shares of 16-column groups; a share is walked in passes of 8 groups, the last one possibly partial —
     // a pass with one wave per SIMD (or a single wave) costs about half a full one, a whole extra round would cost all of it
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
@@ -1190,14 +1129,21 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     }
     b -= a.nb_x4;
     if (b < a.nb_thin) {                                 // w1b[f][k] = k<3 ? W_1[f][k] : b_1[f];  w1t16[r][f] = r<3 ? W_1[f][r] : 0;  zeros
-        for (int gid = b * 256 + threadIdx.x; gid < 16 * H; gid += a.nb_thin * 256) {
+        const int n_thin = 16 * H > a.L * H ? 16 * H : a.L * H;
+        for (int gid = b * 256 + threadIdx.x; gid < n_thin; gid += a.nb_thin * 256) {
             if (gid < 4 * H) {
                 const int f = gid / 4, k = gid % 4;
                 a.w1b[gid] = a.rho * (k < 3 ? a.theta[f * 3 + k] : a.theta[3 * H + f]);
                 if (k == 3) a.b1s[f] = a.rho * a.theta[3 * H + f];
             }
-            const int r = gid / H, f = gid % H;
-            a.w1t16[gid] = r < 3 ? a.rho * a.theta[f * 3 + r] : 0.f;
+            if (gid >= H && gid < a.L * H) {                 // b1s rows 1 .. L-1 = b_2 .. b_L (16 H >= L H is not guaranteed: see the loop bound)
+                const int layer = gid / H, f = gid % H;
+                a.b1s[gid] = a.theta[a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (int64_t)H * H + f];
+            }
+            if (gid < 16 * H) {
+                const int r = gid / H, f = gid % H;
+                a.w1t16[gid] = r < 3 ? a.rho * a.theta[f * 3 + r] : 0.f;
+            }
         }
         if (b == 0) {
             for (int i = threadIdx.x; i < a.nzero; i += 256) a.zero[i] = 0u;
@@ -1413,7 +1359,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     float unscale = 1.f, sb = 1.f, inv_sb = 1.f;        // accumulators -> true values | scale of the B operand being read back
     auto in_layer = [&](int j) -> int { return kFwdDir ? j : a.L - 1 - j; };
     auto bias_ptr = [&](int layer) -> const float* {
-        return layer == 0 ? a.b1s : a.theta + a.off_hid + (int64_t)(layer - 1) * a.hid_stride + (size_t)H * H;   // (b1s: rho b_1 as packed)
+        return a.b1s + (size_t)layer * H;              // [L][H] biases as packed (row 0 = rho b_1)
     };
     auto stash_base = [&](int layer, int T) -> int64_t {
         const int64_t v = (int64_t)layer * a.stash_layer + (int64_t)(16 * T) * a.np;
@@ -1658,15 +1604,8 @@ __device__ __forceinline__ void sweep_w_body(const SweepArgs& a) {
     constexpr int kRow = amax_row<SW, FL>();
     unsigned* lds_amax = reinterpret_cast<unsigned*>(lds_w + 3 * GeoWT<SP>::CHUNKB);
     if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }
-    // A/B knob (off by default): odd workgroups start (a.prio >> 8) x 1024 cycles late.  A layer of this kernel is a compute
-    // phase (the k-loop, 117 k cycles at 125 k points, matrix pipe 84 % busy) followed by a memory phase (the tail burst,
-    // 25-45 k cycles); putting the two halves of the chip half a layer out of step buys only 1.3 % on the step: the burst
-    // is bound by the CU's vector-memory instruction rate (8 waves x 5 wave-instructions per tile, ~20 cycles each), not
-    // by HBM (tools/phase_timeline_wide.py, -DDUDF_SWEEP_DBG=128).
-    if ((blockIdx.x & 1) && (a.prio >> 8) > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), dt = (unsigned long long)(a.prio >> 8) << 10;
-        while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
-    }
+    // (measured and dropped: odd workgroups starting half a layer late, so that one half of the chip is in its compute phase
+    //  — the k-loop — while the other is in its memory phase — the tail burst: +1.3 %)
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)

@@ -1214,11 +1214,11 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     hipLaunchKernelGGL((wgrad_hidden_bf16_kernel<H>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_bf, st, a);   // per-wave split
                     return (int)hipGetLastError();
                 }
-                // DUDF_WGRAD_VAR in {1, 3, 9} (A/B testing; 9 ships): bit 0 conflict-free producer lanes (always on), bit 1 split
-                // interleaved with the MFMA groups, bit 3 progress flags in LDS instead of the stage barrier (three image buffers,
-                // MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe).  The plain producer-lane
-                // order and the static-priority variants (round-2 experiments, measured no faster) are no longer built.
-                static const int var = [] { const char* e = getenv("DUDF_WGRAD_VAR"); return e ? atoi(e) & 15 : 9; }();
+                // The shipped body is VAR 9: conflict-free producer lanes + progress flags in LDS instead of the stage barrier (three
+                // image buffers, MFMAs first, split two images ahead, SIMD partners alternating on the matrix pipe).  Its
+                // barrier-synchronised predecessors (VAR 1, 3) and the static-priority variants are no longer instantiated:
+                // DESIGN.md Appendix A has their numbers.
+                constexpr int var = 9;
                 if (a.p24) {                                                      // 24-bit tile-major operands: their own build
                     if (!(dudf_split_fp16() && a.amax && a.L <= 64 && var == 9 && ntz == 1)) return DUDF_E_UNSUPPORTED;
                     dudf_note_products(PROF_WGRAD_HIDDEN, 3);
@@ -1257,8 +1257,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                         if (e != hipSuccess) return (int)e;
                         attr4 = true;
                     }
-                    static const bool xcd_remap = [] { const char* e = getenv("DUDF_WGRAD_XCD"); return !(e && e[0] == '0'); }();
-                    if (ntz == 4 && xcd_remap && !dudf_deterministic()) {          // 2 x 2 tiles: a group's tiles on one XCD
+                    if (ntz == 4 && !dudf_deterministic()) {                       // 2 x 2 tiles: a group's tiles on one XCD
                         WgradArgs b = a;
                         b.remap_nsplit = nsplit;
                         const int groups = nl * nsplit, grid1 = ((groups + 7) / 8) * 32;
@@ -1268,25 +1267,14 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                     }
                     return (int)hipGetLastError();
                 }
-                if (!attr3) {
-                    hipError_t e = hipSuccess;
+                if (!attr3) {                                                       // bf16x6 (DUDF_SPLIT=bf16), same body
                     const size_t smem_cs = smem_p / 2 * 3 + 512;                     // three buffers + the flags
-                    const void* fns[3] = {reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 1>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 3>),
-                                          reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 9>)};
-                    for (int v = 0; v < 3 && e == hipSuccess; ++v)
-                        e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(v == 2 ? smem_cs : smem_p));
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden_bf16p_kernel<H, 9>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cs);
                     if (e != hipSuccess) return (int)e;
                     attr3 = true;
                 }
-#define DUDF_WG_GO(V) hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, V>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p, st, a)
-                switch (var) {
-                    case 1: DUDF_WG_GO(1); break;
-                    case 3: DUDF_WG_GO(3); break;
-                    case 9: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a); break;
-                    default: hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a); break;
-                }
-#undef DUDF_WG_GO
+                hipLaunchKernelGGL((wgrad_hidden_bf16p_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_p / 2 * 3 + 512, st, a);
                 return (int)hipGetLastError();
             }
         }
@@ -1332,14 +1320,11 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     s.Q = a.Q; s.A = a.A; s.Z = a.Z; s.S = a.S; s.x4 = ws + lo.ws_x4; s.gbar = ws + lo.ws_gbar; s.ybar = ws + lo.ws_ybar;
     s.dtheta = dtheta; s.np = lo.np; s.ncols = lo.ncols; s.stash_layer = lo.stash_layer;
     s.off_wo = lo.off_wo; s.off_bo = lo.off_bo; s.H = lo.H; s.L = lo.L; s.have_g = have_g; s.rho = lo.rho;
-    static const int ppb = [] { const char* e = getenv("DUDF_SMALL_PPB"); const int v = e ? atoi(e) : 4096; return v >= 64 ? v : 4096; }();   // A/B testing: with 16 feature-quad groups 4096 columns per block is best (0.096 ms;
-                                                                       // round 1: 1024 columns x 4 groups, 0.156 ms)
-    s.pts_per_block = dudf_deterministic() ? (int)lo.ncols : ppb;
+    s.pts_per_block = dudf_deterministic() ? (int)lo.ncols : 4096;     // with 16 feature-quad groups 4096 columns per block measured best (0.096 ms; 1024 x 4 groups: 0.156)
     const int grid = (int)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block);
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
-    static const int gy_env = [] { const char* e = getenv("DUDF_SMALL_GY"); return e ? atoi(e) : 0; }();   // A/B testing
     const int fqn = lo.H / 4;                                              // feature quads; a block's 4 waves take one each per round:
-    const int gy = gy_env > 0 ? gy_env : (fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1));   // up to 16 groups -> more loads in flight per CU
+    const int gy = fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1);              // up to 16 groups -> more loads in flight per CU
     if (lo.p24 && (DUDF_P24_ARRAYS & 1)) {          // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
         s.pts_per_block = (s.pts_per_block + 15) / 16 * 16;
         hipLaunchKernelGGL(wgrad_small_p24_kernel, dim3((unsigned)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block), lo.H / 16), dim3(256), 0, st, s);
