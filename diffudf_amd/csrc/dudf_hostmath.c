@@ -4,6 +4,3 @@
 void dudf_host_sincos(const float* x, float* s, float* c, long n) {
     for (long i = 0; i < n; ++i) dudf_sincos(x[i], &s[i], &c[i]);
 }
-void dudf_host_sincos_quarter(const float* t, float* s, float* c, long n) {
-    for (long i = 0; i < n; ++i) dudf_sincos_quarter(t[i], &s[i], &c[i]);
-}

@@ -55,22 +55,3 @@ DUDF_HD void dudf_sincos(float x, float* s_out, float* c_out) {
     dudf_quadrant(n, sr, cr, s_out, c_out);
 }
 
-// The same pair for an argument given in QUARTER TURNS: t = x * 2/pi.  The forward sweep folds w0 * 2/pi into the scale and
-// the bias of its pre-activation FMA (t = acc * (2^-k w0 2/pi) + b w0 2/pi: one rounding where x = w0 * (acc 2^-k + b) had
-// two), so the reduction is k = rint(t), d = t - k (exact), r = d * pi/2 in two pieces: two instructions fewer per value
-// than multiply + Cody-Waite.  Same polynomials, same quadrant logic; max absolute error against sin / cos of the EXACT
-// t * pi/2 is the same 9.4e-8 (tests/test_host_math.py).
-DUDF_HD void dudf_sincos_quarter(float t, float* s_out, float* c_out) {
-    const float k = rintf(t);
-    const float d = t - k;                                       // |d| <= 1/2, exact
-    const float r = fmaf(d, 1.57079637050628662109375f, d * -4.37113900018624283e-8f);
-    const int n = (int)k;
-    const float r2 = r * r;
-    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(r2, ps, -1.6666654611e-1f);
-    const float sr = fmaf(r * r2, ps, r);
-    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(r2, pc, 4.166664568298827e-2f);
-    const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
-    dudf_quadrant(n, sr, cr, s_out, c_out);
-}

@@ -46,9 +46,6 @@
 #ifndef DUDF_W_RELAY_NT
 #define DUDF_W_RELAY_NT 0                    // 512-wide kernel: 1 = non-temporal stores for the relay array as well (rounds 2-3)
 #endif
-#ifndef DUDF_QT
-#define DUDF_QT 1                            // fp16x3 forward sweep of the plain columns: sine argument in quarter turns from ONE FMA (A/B: 0)
-#endif
 #ifndef DUDF_TAIL_TOP
 #define DUDF_TAIL_TOP (SP != 0 && BS == SWEEP_FWD)   // early half: tail in front of the step's DMA pieces
 #endif
@@ -238,7 +235,6 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     const bool isv = !HS || (is_jet(SW) ? li == 0 : (lane & 3) == 0);   // value channel (always, on the plain path)
     const int nhid = a.L - 1;                          // hidden x hidden layers (>= 1 here)
     constexpr bool kFwdDir = (BS == SWEEP_FWD || BS == SWEEP_ADJ_FWD);
-    const float kQT = DUDF_QT ? a.w0 * 0.636619772367581343f : 1.f;   // fp16x3 forward sweep of the plain columns: pre-activations in quarter turns
 
     f32x4 acc[G::NT], prev[G::NT];                     // this layer's accumulators / the previous layer's, tails pending
     const int64_t p = (int64_t)(g_first + wave) * 16 + li;
@@ -373,10 +369,13 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             const f32x4 us = {unscale, unscale, unscale, unscale};
             e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
             e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
-        } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: w0 z 2/pi = (2^-k w0 2/pi) (2^k W h) + (w0 2/pi) b: one FMA per value,
-            const float uq = unscale * kQT;                 // in quarter turns (the biases in LDS carry the factor: sweep_body_b)
-            e0 = epilogue<SW, FL, false, P24 != 0, DUDF_QT != 0>(a, __builtin_elementwise_fma(z0, f32x4{uq, uq, uq, uq}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, false, P24 != 0, DUDF_QT != 0>(a, __builtin_elementwise_fma(z1, f32x4{uq, uq, uq, uq}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+        } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
+            // (measured and dropped, round 4: w0 2/pi folded into this FMA and the biases, sin / cos from the argument in quarter
+            //  turns — two instructions per value fewer, -2 % on this sweep, value error unchanged; but the ROUNDED constant
+            //  w0 2/pi is off by 2e-8, the same way for every pre-activation of the network: a coherent error that the 12-step
+            //  beetle trajectory amplified to 1e-3 where the reference's own, unbiased, fp32 roundings stay at 2e-7)
+            e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
             e0 = epilogue<SW, FL, false, P24 != 0>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
             e1 = epilogue<SW, FL, false, P24 != 0>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
@@ -810,9 +809,9 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                   // ONE tail pair per wave and layer
             f32x4 z = prev[u];
-            if constexpr (BS == SWEEP_FWD) { const float uq = DUDF_QT ? unscale * (a.w0 * 0.636619772367581343f) : unscale; z = __builtin_elementwise_fma(z, f32x4{uq, uq, uq, uq}, bs[u]); }
+            if constexpr (BS == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[u]);
             else z *= unscale;
-            e[u] = epilogue<SW, FL, kTrackE, P24 != 0, BS == SWEEP_FWD && DUDF_QT != 0>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
+            e[u] = epilogue<SW, FL, kTrackE, P24 != 0>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
         }
         if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) lds_max_wave(lds_amax + lin, tk.t); tk.t = 0.f; }
         if constexpr (kTrackE) {
@@ -925,13 +924,7 @@ __device__ __forceinline__ void sweep_body_b(const SweepArgs& a, const int bid, 
     if constexpr (kRow >= 0) { if (threadIdx.x < kMaxAmaxLayers) lds_amax[threadIdx.x] = 0u; }   // (sweep_tile_b starts with a barrier)
     if constexpr (SP != 0 && base_of(SW) == SWEEP_FWD) {     // b_1 .. b_L behind the three weight buffers (read by the tails)
         float* lb = reinterpret_cast<float*>(lds_b + 3 * GeoB<H, SP>::CHUNKB);
-        // plain columns: times w0 2/pi — their tail forms the sine's argument in quarter turns with one FMA (dudf_sincos_quarter)
-        const float bq = (DUDF_QT && SW == SWEEP_FWD) ? a.w0 * 0.636619772367581343f : 1.f;
-        for (int i = threadIdx.x; i < a.L * H; i += 64 * NWB) {
-            const int layer = i / H, f = i - layer * H;
-            lb[i] = bq * a.b1s[i];                        // [L][H] biases as packed (row 0 = rho b_1)
-            (void)layer; (void)f;
-        }
+        for (int i = threadIdx.x; i < a.L * H; i += 64 * NWB) lb[i] = a.b1s[i];      // [L][H] biases as packed (row 0 = rho b_1)
     }
     // balanced shares of 16-column groups; a share is walked in passes of 8 groups, the last one possibly partial —
     // a pass with one wave per SIMD (or a single wave) costs about half a full one, a whole extra round would cost all of it
@@ -1430,7 +1423,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             else if constexpr (BS == SWEEP_FWD) z = (SP != 0 ? z * unscale : z) + (isv ? bs[s] : zero4);   // the bias: value channel only
             else if constexpr (SP != 0) z *= unscale;
             // (RL: the array the next layer reads its operand back from keeps the default cache policy — DUDF_W_RELAY_NT=1: A/B)
-            const f32x4 e = epilogue<SW, FL, false, false, false, !DUDF_W_RELAY_NT>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
+            const f32x4 e = epilogue<SW, FL, false, false, !DUDF_W_RELAY_NT>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
             if constexpr (wide_relay_store<SW, FL>()) { if constexpr (DUDF_W_RELAY_NT) DUDF_ST(a.S, stash_base(layer, T), vo, e); else DUDF_ST_CACHED(a.S, stash_base(layer, T), vo, e); }
             if constexpr (kColScale) dudf_track(cmax, e);
             if (T + PD < G::NT) ld(T + PD, s);

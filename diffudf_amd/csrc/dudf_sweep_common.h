@@ -43,30 +43,6 @@ __device__ __forceinline__ void dudf_sincos2(dudf_f2 x, dudf_f2& s_out, dudf_f2&
     }
 }
 
-// ... for an argument in quarter turns (dudf_sincos_quarter: the fp16x3 forward sweep of the plain columns)
-__device__ __forceinline__ void dudf_sincos2_q(dudf_f2 t, dudf_f2& s_out, dudf_f2& c_out) {
-#if DUDF_SWEEP_DBG & 64
-    s_out = t; c_out = t * 0.5f; return;
-#endif
-    const dudf_f2 k = {rintf(t.x), rintf(t.y)};
-    const dudf_f2 d = t - k;
-    const dudf_f2 r = __builtin_elementwise_fma(d, (dudf_f2)(1.57079637050628662109375f), d * (dudf_f2)(-4.37113900018624283e-8f));
-    const dudf_i2 n = {(int)k.x, (int)k.y};
-    const dudf_f2 r2 = r * r;
-    dudf_f2 ps = __builtin_elementwise_fma(r2, (dudf_f2)(-1.9515295891e-4f), (dudf_f2)(8.3321608736e-3f));
-    ps = __builtin_elementwise_fma(r2, ps, (dudf_f2)(-1.6666654611e-1f));
-    const dudf_f2 sr = __builtin_elementwise_fma(r * r2, ps, r);
-    dudf_f2 pc = __builtin_elementwise_fma(r2, (dudf_f2)(2.443315711809948e-5f), (dudf_f2)(-1.388731625493765e-3f));
-    pc = __builtin_elementwise_fma(r2, pc, (dudf_f2)(4.166664568298827e-2f));
-    const dudf_f2 cr = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (dudf_f2)(-0.5f), (dudf_f2)(1.0f)));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float so, co;
-        dudf_quadrant(n[i], sr[i], cr[i], &so, &co);
-        s_out[i] = so; c_out[i] = co;
-    }
-}
-
 // Stash addressing: `ub` is a WAVE-UNIFORM float offset (layer and tile folded in, lives in SGPRs),
 // `vo` the lane's 32-bit float offset ((quarter*np + point)*4): global_load/store take the saddr form
 // and no per-tile 64-bit address is kept in VGPRs.
@@ -250,9 +226,8 @@ struct LaneOff {
     __device__ __forceinline__ LaneOff(unsigned x, unsigned y, unsigned z) : v(x), c(y), t(z) {}
 };
 
-// QT (forward sweep only): `acc` is the pre-activation in QUARTER TURNS, w0 z 2/pi (constants folded into the caller's FMA)
 // RL: the array that carries this sweep's post-tail values (S / Q / A / Z by sweep) is stored with the default cache policy
-template <int SW, int FL, bool TE = false, bool P24 = false, bool QT = false, bool RL = false>
+template <int SW, int FL, bool TE = false, bool P24 = false, bool RL = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
                                           const LaneOff lo, bool isv, TailTrack& tk) {
     const unsigned vo = lo.v;
@@ -262,8 +237,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
             dudf_f2 sv, cv;
-            if constexpr (QT) dudf_sincos2_q(dudf_f2{acc[t], acc[t + 1]}, sv, cv);
-            else dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
+            dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
             s[t] = sv.x; s[t + 1] = sv.y; c[t] = cv.x; c[t + 1] = cv.y;
         }
         if constexpr (FL & 1) DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo, s);

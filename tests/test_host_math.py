@@ -22,21 +22,6 @@ def test_sincos_absolute_error():
     assert np.abs(c - np.cos(xs)).max() < 1.2e-7
 
 
-def test_sincos_quarter_turn_argument():
-    """dudf_sincos_quarter(t) = (sin, cos)(t * pi/2): what the fp16x3 forward sweep calls with t = w0 z 2/pi formed by ONE
-    FMA (constants folded into its scale and bias).  Same error bound against the exact argument."""
-    lib = ctypes.CDLL(LIB)
-    rng = np.random.default_rng(2)
-    t = np.concatenate([rng.uniform(-40, 40, 2_000_000), rng.uniform(-6400, 6400, 1_000_000), rng.uniform(-1, 1, 500_000),
-                        np.array([0.0, -0.0, 0.5, 1.0, 1.5, 2.0, 30.0, -2.5])]).astype(np.float32)
-    s = np.empty_like(t); c = np.empty_like(t)
-    P = ctypes.POINTER(ctypes.c_float)
-    lib.dudf_host_sincos_quarter(t.ctypes.data_as(P), s.ctypes.data_as(P), c.ctypes.data_as(P), ctypes.c_long(t.size))
-    x = t.astype(np.float64) * (np.pi / 2)
-    assert np.abs(s - np.sin(x)).max() < 1.2e-7
-    assert np.abs(c - np.cos(x)).max() < 1.2e-7
-
-
 def test_siren_init_distributions_and_state_dict_layout():
     """Row A1 (reference src/model.py:7-19, 85-113): first layer ~U(+-1/fan_in), the rest ~U(+-sqrt(6/fan_in)/w0), biases
     nn.Linear's default U(+-1/sqrt(fan_in)); state_dict keys `net.{i}.0.weight|bias`; the parameters are views of
