@@ -1127,8 +1127,9 @@ __global__ __launch_bounds__(256) DUDF_NO_PK void wgrad_small_p24_kernel(WgradSm
 #pragma unroll
     for (int c = 0; c < 4; ++c) { wo[c] = 0.f; w1[c][0] = w1[c][1] = w1[c][2] = w1[c][3] = 0.f; }
     float sy = 0.f;
+    const int nwave = (int)(blockDim.x >> 6);                           // 4; ONE in the deterministic mode (one adder per output)
 #pragma unroll 4
-    for (int64_t g = g0 + wave; g < g1; g += 4) {
+    for (int64_t g = g0 + wave; g < g1; g += nwave) {
         const int64_t p = g * 16 + li;
         const f32x4 z = small_unpack24(reinterpret_cast<const unsigned*>(Z0 + g * 768));
         const f32x4 sl = small_unpack24(reinterpret_cast<const unsigned*>(SL + g * 768));
@@ -1327,7 +1328,8 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     const int gy = fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1);              // up to 16 groups -> more loads in flight per CU
     if (lo.p24 && (DUDF_P24_ARRAYS & 1)) {          // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
         s.pts_per_block = (s.pts_per_block + 15) / 16 * 16;
-        hipLaunchKernelGGL(wgrad_small_p24_kernel, dim3((unsigned)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block), lo.H / 16), dim3(256), 0, st, s);
+        hipLaunchKernelGGL(wgrad_small_p24_kernel, dim3((unsigned)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block), lo.H / 16),
+                           dim3(dudf_deterministic() ? 64 : 256), 0, st, s);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(grid, gy), dim3(256), 0, st, s);

@@ -339,7 +339,9 @@ def test_fp16x3_range_scaling_hessian_quads(hip, scale):
     g1 = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, torch.ones(4, device="cuda"), None, ws, n_hess=n_on).clone()
     gs = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1FULL, 100.0, torch.full((4,), scale, device="cuda"), None, ws, n_hess=n_on)
     assert torch.isfinite(gs).all()
-    assert rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy()) < 5e-6, scale
+    # (24-bit stash: a cotangent scaled by a non-power of two rounds the stashed adjoints at other places — the format's own
+    #  2^-17 per element bounds this self-consistency check there, see test_fp16x3_range_scaling; measured 8.0e-6)
+    assert rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy()) < (5e-6 if hip.stash_mode(cfg) == 0 else 2e-5), scale
     if scale > 1:
         k = 4.0
         P2 = [(w * (k if 0 < i < len(P) - 1 else 1.0), b) for i, (w, b) in enumerate(P)]
