@@ -5,10 +5,6 @@
 #include <string.h>
 #include <vector>
 
-#ifndef DUDF_STASH_DEFAULT_P24
-#define DUDF_STASH_DEFAULT_P24 false
-#endif
-
 // ---- per-kernel HIP-event timing ---------------------------------------------------------------------------
 namespace {
 struct ProfRec { int slot; hipEvent_t e0, e1; };
@@ -72,19 +68,27 @@ bool use_bf16_sweeps() {
 
 }  // namespace
 
-// DUDF_STASH: "17" = every stash array fp32 (rounds 1-3), "17p24" = the backward-only arrays S, Q, R, E, A, Z at 24 bits,
-// tile-major (dudf_internal.h).  The 24-bit format exists in the fp16x3 training kernels of 256-wide networks and in the
-// cooperative-split weight-gradient GEMM; any A/B switch that routes a kernel elsewhere keeps the fp32 stash.
-bool dudf_stash_p24_enabled(int H, int L) {
-    static const bool want = [] {
+// DUDF_STASH (stash format of 256-wide training workspaces; dudf_stash_mode):
+//   "17"    = every array fp32: 17 array-layer units per column (rounds 1-3);
+//   "16"    = R and E at 24 bits, tile-major (dudf_internal.h): 16 units — the DEFAULT: every tolerance holds, the 12-step beetle
+//             trajectory included (3e-7), step -4 %;
+//   "17p24" = S, Q, A, Z as well (13.75 units, step -9 %): opt-in — every single-step tolerance holds, but 2^-17 noise on the
+//             weight-gradient GEMM's operands moves the beetle trajectory by 4e-4 (bar 1e-4; tests/test_stash_p24_gpu.py).
+// The 24-bit arrays exist in the fp16x3 training kernels of 256-wide networks (R, E) and in the cooperative-split
+// weight-gradient GEMM (S, Q, A, Z); an A/B switch that routes a kernel elsewhere drops the corresponding bit.
+int dudf_stash_p24_enabled(int H, int L) {
+    static const int want = [] {
         const char* e = getenv("DUDF_STASH");
-        const bool on = e ? strstr(e, "p24") != nullptr : DUDF_STASH_DEFAULT_P24;
-        if (!on) return false;
+        int m = 2;
+        if (e && strstr(e, "p24")) m = 3;
+        else if (e && strcmp(e, "17") == 0) m = 0;
+        else if (e && strcmp(e, "16") != 0) m = 2;
+        if (!(use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47)) return 0;
         const char* w = getenv("DUDF_WGRAD");
-        if (w && w[0]) return false;                                        // f32 / bf16w weight-gradient kernels read fp32 rows
-        return use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47;
+        if (w && w[0]) m &= 2;                                              // f32 / bf16w weight-gradient kernels read fp32 rows
+        return m;
     }();
-    return want && H == 256 && L >= 2 && L <= 32;
+    return (H == 256 && L >= 2 && L <= 32) ? want : 0;
 }
 
 namespace {
@@ -620,8 +624,8 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
     const DudfLayout& lo = c.lo;
     const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
     if (which < 0 || which > 7) return DUDF_E_BADMODE;
-    // S, Q, A, Z | E, R: 24-bit tile-major in a p24 workspace (DUDF_P24_ARRAYS)
-    const bool b24 = lo.p24 && which != 1 && which != 7 && (DUDF_P24_ARRAYS & ((which == 3 || which == 6) ? 2 : 1));
+    // S, Q, A, Z (bit 0) | E, R (bit 1): 24-bit tile-major
+    const bool b24 = which != 1 && which != 7 && (lo.p24 & ((which == 3 || which == 6) ? 2 : 1)) != 0;
     return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st, which == 1, b24);   // C: one copy per quad
 }
 
@@ -640,7 +644,7 @@ int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, 
 int dudf_stash_mode(const dudf_net_cfg* cfg) {
     DudfLayout lo;
     if (dudf_make_layout(cfg, 1, 0, &lo)) return -1;
-    return lo.p24 ? 1 : 0;
+    return lo.p24;
 }
 
 }  // extern "C"

@@ -60,13 +60,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //     byte offset of granule (layer, f, p) = (((layer*(H/16) + f/16)*(np/16) + p/16)*64 + 16*((f%16)/4) + p%16)*12
 // dwords of a granule (values v0..v3 = features 4q..4q+3, u_i = bits(v_i) + 0x80):
 //     d0 = u0>>8 | u1.byte1<<24,  d1 = u1>>16 | (u2>>8)<<16,  d2 = u2.byte3 | (u3>>8)<<8
-#ifndef DUDF_P24_ARRAYS
-#define DUDF_P24_ARRAYS 3     // which arrays a p24 workspace keeps at 24 bits: bit 0 = S, Q, A, Z (the weight-gradient GEMM's operands), bit 1 = R, E
-#endif
 struct DudfLayout {
     int H, L;
     float rho;               // w0 / ww (dudf_net_cfg): the first layer is packed times rho, `w0` below is the ONE frequency the kernels run (ww)
-    int p24;                 // 1: S, Q, R, E, A, Z are 24-bit tile-major arrays (see above)
+    int p24;                 // which arrays are 24-bit tile-major (see above): bit 0 = S, Q, A, Z (the weight-gradient GEMM's operands), bit 1 = R, E
     float w0;
     int64_t n, n_h;          // points, and how many of them (the first n_h) take the Hessian path
     int64_t ncol_h, ncol_n;  // padded column counts of the two ranges
@@ -83,7 +80,7 @@ struct DudfLayout {
 
 // 24-bit stash selected for this network?  (dudf_api.hip: DUDF_STASH, and every kernel of the step must be the fp16x3 build
 // that reads / writes it)
-bool dudf_stash_p24_enabled(int H, int L);
+int dudf_stash_p24_enabled(int H, int L);   // the mask (0, 2 or 3)
 
 static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo, int query_only = 0) {
     if (!cfg || cfg->n_in != 3 || cfg->n_hidden_layers < 1) return DUDF_E_BADCFG;
@@ -94,7 +91,7 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     const float ww = cfg->ww > 0.f ? cfg->ww : cfg->w0;
     lo->H = H; lo->L = L; lo->w0 = ww; lo->rho = cfg->w0 / ww;
     lo->n = n; lo->n_h = n_h;
-    lo->p24 = (!query_only && dudf_stash_p24_enabled(H, L)) ? 1 : 0;
+    lo->p24 = query_only ? 0 : dudf_stash_p24_enabled(H, L);
     auto pad = [](int64_t c) { return (c + DUDF_COL_PAD - 1) / DUDF_COL_PAD * DUDF_COL_PAD; };
     lo->ncol_h = pad(4 * n_h);
     lo->ncol_n = pad(n - n_h);
@@ -134,8 +131,8 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     lo->ws_ybar = take(lo->np); lo->ws_gbar = take(4 * lo->np);
     lo->stash_layer = (int64_t)H * lo->np;
     const int64_t stash = (int64_t)L * lo->stash_layer;
-    const int64_t stash_b = (lo->p24 && (DUDF_P24_ARRAYS & 1)) ? stash / 4 * 3 : stash;   // the backward-only arrays: 12 instead of 16 bytes per granule
-    const int64_t stash_r = (lo->p24 && (DUDF_P24_ARRAYS & 2)) ? stash / 4 * 3 : stash;   // R, E
+    const int64_t stash_b = (lo->p24 & 1) ? stash / 4 * 3 : stash;   // S, Q, A, Z: 12 instead of 16 bytes per granule
+    const int64_t stash_r = (lo->p24 & 2) ? stash / 4 * 3 : stash;   // R, E
     lo->ws_S = take(stash_b); lo->ws_C = take(stash);
     lo->ws_ZS = n_h > 0 ? take(stash) : lo->ws_S;
     if (query_only) {        // value / df/dx / Hessian queries only ever touch S, C, ZS: 16-24 KB per column instead of 56-64
@@ -181,7 +178,7 @@ struct SweepArgs {
     int L; float w0;
     int store_s, store_c, train;   // what the sweep has to leave behind
     int have_e;                    // reverse adjoint sweep: e_l was produced by SWEEP_ADJ_FWD
-    int p24;                       // S, Q, R, E, A, Z are 24-bit tile-major arrays (DudfLayout::p24)
+    int p24;                       // which stash arrays are 24-bit tile-major (DudfLayout::p24: bit 0 = S, Q, A, Z, bit 1 = R, E)
 };
 
 enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,

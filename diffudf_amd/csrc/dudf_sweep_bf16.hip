@@ -225,7 +225,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     using G = GeoB<H, SP>;
     constexpr int NPC = G::NPC;
     static_assert(SP == 0 || SW <= SWEEP_FWD_J, "fp16x3: plain columns, Hessian quads, jets");
-    static_assert(P24 == 0 || (SP != 0 && H == 256 && !is_jet(SW)), "24-bit stash: the fp16x3 training kernels of 256-wide layers");
+    static_assert(P24 == 0 || ((P24 == 2 || P24 == 3) && SP != 0 && H == 256 && !is_jet(SW)), "24-bit stash arrays (mask 2: R, E; 3: all six): the fp16x3 training kernels of 256-wide layers");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -348,8 +348,8 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo,   // C: one copy per quad
                      P24 ? (unsigned)(((p >> 4) * 64 + lane) * 12) : 0u);                                         // 24-bit tile-major arrays
     auto load_ops = [&](int layer, int kb, TailOps& o) {
-        epilogue_loads<SW, FL, P24 != 0>(a, stash_base(layer, 2 * kb), vl, o.o1a, o.o2a, o.o3a);
-        epilogue_loads<SW, FL, P24 != 0>(a, stash_base(layer, 2 * kb + 1), vl, o.o1b, o.o2b, o.o3b);
+        epilogue_loads<SW, FL, P24>(a, stash_base(layer, 2 * kb), vl, o.o1a, o.o2a, o.o3a);
+        epilogue_loads<SW, FL, P24>(a, stash_base(layer, 2 * kb + 1), vl, o.o1b, o.o2b, o.o3b);
         if constexpr (BS == SWEEP_FWD && SP != 0) {
             // fp16x3: every layer's bias sits in LDS behind the weight buffers (sweep_body_b) — a vector-memory instruction
             // costs its wave ~100 cycles of issue when the CU's eight waves contend (s_memtime timeline: the two bias loads
@@ -367,24 +367,24 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         const f32x4 zero = {0, 0, 0, 0};
         if constexpr (BS == SWEEP_FWD && SP != 0 && HS) {   // quads: the bias only in the value channel; `unscale` is this column's
             const f32x4 us = {unscale, unscale, unscale, unscale};
-            e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24>(a, __builtin_elementwise_fma(z0, us, isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24>(a, __builtin_elementwise_fma(z1, us, isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD && SP != 0) {  // plain columns: z = 2^-k (2^k W h) + b, one FMA per value
             // (measured and dropped, round 4: w0 2/pi folded into this FMA and the biases, sin / cos from the argument in quarter
             //  turns — two instructions per value fewer, -2 % on this sweep, value error unchanged; but the ROUNDED constant
             //  w0 2/pi is off by 2e-8, the same way for every pre-activation of the network: a coherent error that the 12-step
             //  beetle trajectory amplified to 1e-3 where the reference's own, unbiased, fp32 roundings stay at 2e-7)
-            e0 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, false, P24 != 0>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24>(a, __builtin_elementwise_fma(z0, f32x4{unscale, unscale, unscale, unscale}, o.ba), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24>(a, __builtin_elementwise_fma(z1, f32x4{unscale, unscale, unscale, unscale}, o.bb), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (BS == SWEEP_FWD) {      // z = W h + b only in the value channel
-            e0 = epilogue<SW, FL, false, P24 != 0>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, false, P24 != 0>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24>(a, z0 + (isv ? o.ba : zero), zero, zero, zero, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24>(a, z1 + (isv ? o.bb : zero), zero, zero, zero, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else if constexpr (kColScale) {            // accumulators -> true values first (2^-k_j / sb of the matrix that made them)
-            e0 = epilogue<SW, FL, kTrackE, P24 != 0>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, kTrackE, P24 != 0>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, kTrackE, P24>(a, z0 * unscale, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, kTrackE, P24>(a, z1 * unscale, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         } else {
-            e0 = epilogue<SW, FL, false, P24 != 0>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
-            e1 = epilogue<SW, FL, false, P24 != 0>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
+            e0 = epilogue<SW, FL, false, P24>(a, z0, o.o1a, o.o2a, o.o3a, stash_base(layer, 2 * kb), vl, isv, tmax);
+            e1 = epilogue<SW, FL, false, P24>(a, z1, o.o1b, o.o2b, o.o3b, stash_base(layer, 2 * kb + 1), vl, isv, tmax);
         }
     };
     auto pin_ops = [&](TailOps& o) {                    // make the compiler wait for these loads HERE
@@ -771,7 +771,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
     auto load_ops = [&](int layer) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            epilogue_loads<SW, FL, P24 != 0>(a, stash_base(layer, T0 + u), vo, o1[u], o2[u], o3[u]);
+            epilogue_loads<SW, FL, P24>(a, stash_base(layer, T0 + u), vo, o1[u], o2[u], o3[u]);
             if constexpr (BS == SWEEP_FWD)
                 bs[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + 3 * G::CHUNKB) + layer * H + 16 * (T0 + u) + 4 * q);
         }
@@ -811,7 +811,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
             f32x4 z = prev[u];
             if constexpr (BS == SWEEP_FWD) z = __builtin_elementwise_fma(z, f32x4{unscale, unscale, unscale, unscale}, bs[u]);
             else z *= unscale;
-            e[u] = epilogue<SW, FL, kTrackE, P24 != 0>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
+            e[u] = epilogue<SW, FL, kTrackE, P24>(a, z, o1[u], o2[u], o3[u], stash_base(lin, T0 + u), vo, true, tk);
         }
         if constexpr (kRow >= 0) { if (lin < kMaxAmaxLayers) lds_max_wave(lds_amax + lin, tk.t); tk.t = 0.f; }
         if constexpr (kTrackE) {
@@ -969,11 +969,16 @@ template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
-// ... and the fp16x3 builds that keep the backward-only stash arrays at 24 bits, tile-major (dudf_internal.h "p24"; training variants)
+// ... and the fp16x3 builds that keep stash arrays at 24 bits, tile-major (dudf_internal.h "p24"; training variants):
+// f16r: R and E (mask 2, the default stash of 256-wide networks); f16p: S, Q, A, Z as well (mask 3, DUDF_STASH=17p24)
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_f16p_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 1>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64 * NWB) void sweep_f16r_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 2>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16p_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 1>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16r_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 2>(a, blockIdx.x, gridDim.x); }
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_f16p_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 3>(a, blockIdx.x, gridDim.x); }
+template <int H, int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16p_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 3>(a, blockIdx.x, gridDim.x); }
 // Pair launch (a batch with Hessian-path points: `loss_s1` with its eigenvector term, the reference's shipped recipe).  A sweep
 // then has two column ranges — the quads (variant SWQ; fp16x3 or, SPQ = 0, bf16x6) and the plain columns (fp16x3, variant SWP) — which used to be
 // two launches of <= 256 persistent workgroups each: at the reference's batch (29 970 points = 312 + 156 tiles of 128 columns)
@@ -1205,23 +1210,26 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         constexpr size_t smem_o = w3 + kMaxAmaxLayers * sizeof(unsigned) + oct;   // + the per-layer running maxima
         bool done = true;
         // 24-bit tile-major stash (SweepArgs::p24, H = 256): the training variants have a build of their own
-#define DUDF_GO_HP(SW, FL, KERNEL, KERNELP, SMEM_MAX, SMEM)                                                 \
+#define DUDF_GO_HP(SW, FL, KERNEL, KERNELR, KERNELP, SMEM_MAX, SMEM)                                        \
         do {                                                                                                    \
             bool p_ = false;                                                                                    \
-            if constexpr (H == 256) { if (a.p24) { DUDF_GO_H(SW, FL, KERNELP, SMEM_MAX, SMEM); p_ = true; } }   \
+            if constexpr (H == 256) {                                                                           \
+                if (a.p24 == 3) { DUDF_GO_H(SW, FL, KERNELP, SMEM_MAX, SMEM); p_ = true; }                      \
+                else if (a.p24 == 2) { DUDF_GO_H(SW, FL, KERNELR, SMEM_MAX, SMEM); p_ = true; }                 \
+            }                                                                                                   \
             if (!p_) { if (a.p24) return DUDF_E_UNSUPPORTED; DUDF_GO_H(SW, FL, KERNEL, SMEM_MAX, SMEM); }       \
         } while (0)
         if (which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {
-            if (a.store_s && a.store_c) DUDF_GO_HP(SWEEP_FWD, 3, DUDF_FWD_F16_KERNEL, sweep_f16p_np_kernel, smem_fmax, smem_f);
+            if (a.store_s && a.store_c) DUDF_GO_HP(SWEEP_FWD, 3, DUDF_FWD_F16_KERNEL, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_fmax, smem_f);
             else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
             else if (!a.store_s) DUDF_GO_H(SWEEP_FWD, 0, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
             else return DUDF_E_BADMODE;
         } else if (which == SWEEP_REV) {
-            if (a.train) DUDF_GO_HP(SWEEP_REV, 1, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_REV, 0, sweep_f16_kernel, smem_o, smem_o);
+            if (a.train) DUDF_GO_HP(SWEEP_REV, 1, sweep_f16_kernel, sweep_f16r_kernel, sweep_f16p_kernel, smem_o, smem_o); else DUDF_GO_H(SWEEP_REV, 0, sweep_f16_kernel, smem_o, smem_o);
         } else if (which == SWEEP_ADJ_FWD) {
-            DUDF_GO_HP(SWEEP_ADJ_FWD, 0, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o);
+            DUDF_GO_HP(SWEEP_ADJ_FWD, 0, sweep_f16_kernel, sweep_f16r_kernel, sweep_f16p_kernel, smem_o, smem_o);
         } else if (which == SWEEP_ADJ_REV && (!a.have_e || (a.ebound && ((a.split >> SWEEP_ADJ_FWD) & 1)))) {
-            if (a.have_e) DUDF_GO_HP(SWEEP_ADJ_REV, 1, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o); else DUDF_GO_HP(SWEEP_ADJ_REV, 0, sweep_f16_kernel, sweep_f16p_kernel, smem_o, smem_o);
+            if (a.have_e) DUDF_GO_HP(SWEEP_ADJ_REV, 1, sweep_f16_kernel, sweep_f16r_kernel, sweep_f16p_kernel, smem_o, smem_o); else DUDF_GO_HP(SWEEP_ADJ_REV, 0, sweep_f16_kernel, sweep_f16r_kernel, sweep_f16p_kernel, smem_o, smem_o);
         } else {
             done = false;
         }
@@ -1236,10 +1244,10 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         const size_t smem_fq = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         constexpr size_t smem_fqmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         bool done = true;
-        if (which == SWEEP_FWD_H) { if (a.store_s) DUDF_GO_HP(SWEEP_FWD_H, 1, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_fqmax, smem_fq); else DUDF_GO_H(SWEEP_FWD_H, 0, sweep_f16_np_kernel, smem_fqmax, smem_fq); }
-        else if (which == SWEEP_REV_H) { if (a.train) DUDF_GO_HP(SWEEP_REV_H, 1, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q); else DUDF_GO_H(SWEEP_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q); }
-        else if (which == SWEEP_ADJ_FWD_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
-        else if (which == SWEEP_ADJ_REV_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
+        if (which == SWEEP_FWD_H) { if (a.store_s) DUDF_GO_HP(SWEEP_FWD_H, 1, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_fqmax, smem_fq); else DUDF_GO_H(SWEEP_FWD_H, 0, sweep_f16_np_kernel, smem_fqmax, smem_fq); }
+        else if (which == SWEEP_REV_H) { if (a.train) DUDF_GO_HP(SWEEP_REV_H, 1, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q); else DUDF_GO_H(SWEEP_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q); }
+        else if (which == SWEEP_ADJ_FWD_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
+        else if (which == SWEEP_ADJ_REV_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_REV_H, 0, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
         else done = false;
         if (done) return (int)hipGetLastError();
     }
@@ -1752,11 +1760,17 @@ int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq0, const SweepArg
     const size_t sq = q16 ? w3 + (base == SWEEP_FWD ? (size_t)aq.L * 256 * sizeof(float) : 0) + kMaxAmaxLayers * sizeof(unsigned) : kPairSmemQ;
     const size_t smem = sq > sp ? sq : sp;
     if (ap.p24 != aq.p24 || (ap.p24 && !q16)) return DUDF_E_UNSUPPORTED;   // (the 24-bit stash needs the quads on fp16x3 too: dudf_stash_p24_enabled)
-    if (ap.p24) switch (base) {
-        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 1>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 1>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 1>(aq, ap, smem, nbq, nbp, st);
-        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 1>(aq, ap, smem, nbq, nbp, st);
+    if (ap.p24 == 3) switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 3>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 3>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 3>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 3>(aq, ap, smem, nbq, nbp, st);
+    }
+    if (ap.p24 == 2) switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 2>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 2>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 2>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 2>(aq, ap, smem, nbq, nbp, st);
     }
     if (q16) switch (base) {
         case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1>(aq, ap, smem, nbq, nbp, st);

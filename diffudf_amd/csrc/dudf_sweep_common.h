@@ -121,11 +121,23 @@ __device__ __forceinline__ dudf_u3 dudf_dbg_any3() { dudf_u3 z; asm volatile("" 
 #else
 #define DUDF_ST_CACHED(arr, ub, vo, val) (*DUDF_AT(arr, ub, vo) = (f32x4)(val))
 #endif
+// The three dwords of a 24-bit granule as they come from memory (in .xyz of an f32x4): epilogue_loads must not unpack — the
+// operands are requested two steps ahead between scheduling fences, and an unpack next to the load makes the wave wait for the
+// data right there (measured: the adjoint reverse sweep got 9 % SLOWER reading 25 % fewer bytes); epilogue() unpacks at use.
+#if DUDF_SWEEP_DBG & 2
+#define DUDF_LD24RAW(arr, ub, vt) dudf_dbg_any()
+#else
+// (the constant fourth lane costs nothing: it folds; an UNDEFINED lane made hipcc spill three values inside the adjoint forward
+//  sweep's k-block step instead of one)
+__device__ __forceinline__ f32x4 dudf_raw3(const dudf_u3 d) { return f32x4{__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), 0.f}; }
+#define DUDF_LD24RAW(arr, ub, vt) dudf_raw3(__builtin_nontemporal_load(DUDF_CAT24(arr, ub, vt)))
+#endif
+__device__ __forceinline__ f32x4 p24_unpack_raw(const f32x4 r) { return p24_unpack(dudf_u3{__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2])}); }
 // a backward-only array in the format of this build: P (compile-time) = 24-bit tile-major, else fp32 rows
 #define DUDF_STB(P, arr, ub, lo, val) do { if constexpr (P) DUDF_ST24(arr, ub, (lo).t, val); else DUDF_ST(arr, ub, (lo).v, val); } while (0)
 // ... or, RL (compile-time): this array is the caller's relay — default cache policy
 #define DUDF_STR(RL, P, arr, ub, lo, val) do { if constexpr (RL) DUDF_ST_CACHED(arr, ub, (lo).v, val); else DUDF_STB(P, arr, ub, lo, val); } while (0)
-#define DUDF_LDB(P, arr, ub, lo) ((P) ? DUDF_LD24(arr, ub, (lo).t) : DUDF_LD(arr, ub, (lo).v))
+#define DUDF_LDB(P, arr, ub, lo) ((P) ? DUDF_LD24RAW(arr, ub, (lo).t) : DUDF_LD(arr, ub, (lo).v))     // (P: raw, unpacked by epilogue())
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
 // (the empty asm pins the DPP source to an ARCHITECTURAL vector register: in the 512-register kernels of the 512-wide
@@ -227,10 +239,17 @@ struct LaneOff {
 };
 
 // RL: the array that carries this sweep's post-tail values (S / Q / A / Z by sweep) is stored with the default cache policy
-template <int SW, int FL, bool TE = false, bool P24 = false, bool RL = false>
+// P24: which arrays are 24-bit tile-major in this build (DudfLayout::p24): bit 0 = S, Q, A, Z; bit 1 = R, E
+template <int SW, int FL, bool TE = false, int P24 = 0, bool RL = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
                                           const LaneOff lo, bool isv, TailTrack& tk) {
     const unsigned vo = lo.v;
+    // operands that arrive as raw 24-bit granules (epilogue_loads): S in the reverse sweep, R in the adjoint forward sweeps,
+    // E in the adjoint reverse sweeps
+    if constexpr ((P24 & 1) != 0 && SW == SWEEP_REV && (FL & 1)) o2 = p24_unpack_raw(o2);
+    if constexpr ((P24 & 2) != 0 && SW == SWEEP_ADJ_FWD) o2 = p24_unpack_raw(o2);
+    if constexpr ((P24 & 2) != 0 && SW == SWEEP_ADJ_REV && (FL & 1)) o2 = p24_unpack_raw(o2);
+    if constexpr ((P24 & 2) != 0 && (SW == SWEEP_ADJ_FWD_H || SW == SWEEP_ADJ_REV_H)) o3 = p24_unpack_raw(o3);
     f32x4 out;
     if constexpr (SW == SWEEP_FWD) {
         f32x4 s, c;
@@ -240,24 +259,24 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             dudf_sincos2(dudf_f2{a.w0 * acc[t], a.w0 * acc[t + 1]}, sv, cv);
             s[t] = sv.x; s[t + 1] = sv.y; c[t] = cv.x; c[t + 1] = cv.y;
         }
-        if constexpr (FL & 1) DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo, s);
+        if constexpr (FL & 1) DUDF_STR(RL, (P24 & 1) != 0, a.S, ub, lo, s);
         if constexpr (FL & 2) DUDF_ST(a.C, ub, vo, c);
         out = s;
     } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
         out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
         if constexpr (FL & 1) {
-            DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Q, ub, lo, out);
-            DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
+            DUDF_STR(RL, (P24 & 1) != 0, a.Q, ub, lo, out);
+            DUDF_STB((P24 & 2) != 0, a.R, ub, lo, (a.w0 * a.w0) * o2 * acc);   // r_l = w0^2 s_l a_l
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD) {      // acc = Q_l, o1 = c_l, o2 = r_l
         out = a.w0 * o1 * acc;                       // A_l = w0 c_l Q_l
-        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.A, ub, lo, out);
+        DUDF_STR(RL, (P24 & 1) != 0, a.A, ub, lo, out);
         const f32x4 ev = o2 * acc;                   // e_l = r_l Q_l
-        DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo, ev);
+        DUDF_STB((P24 & 2) != 0, a.E, ub, lo, ev);
         if constexpr (TE) dudf_track(tk.e, ev);      // (per column: what bounds zbar_l in the fp16x3 adjoint reverse sweep)
     } else if constexpr (SW == SWEEP_ADJ_REV) {      // acc = hbar_l, o1 = c_l, o2 = e_l
         out = a.w0 * o1 * acc - o2;                  // zbar_l
-        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Z, ub, lo, out);
+        DUDF_STR(RL, (P24 & 1) != 0, a.Z, ub, lo, out);
     } else if constexpr (SW == SWEEP_FWD_H) {
         f32x4 c, zs;
 #pragma unroll
@@ -270,7 +289,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
         }
         DUDF_ST(a.C, ub, lo.c, c);   // one copy per quad (LaneOff): the four lanes hold the same bits and write the same granule — no branch
         DUDF_ST(a.ZS, ub, vo, zs);
-        if constexpr (FL & 1) DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo, out);
+        if constexpr (FL & 1) DUDF_STR(RL, (P24 & 1) != 0, a.S, ub, lo, out);
     } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -278,8 +297,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = isv ? a.w0 * o1[t] * acc[t] : a.w0 * (o1[t] * acc[t] - a.w0 * sv * o2[t] * a0);
         }
         if constexpr (FL & 1) {
-            DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Q, ub, lo, out);
-            DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo, acc);
+            DUDF_STR(RL, (P24 & 1) != 0, a.Q, ub, lo, out);
+            DUDF_STB((P24 & 2) != 0, a.R, ub, lo, acc);
         }
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {    // o1 = c, o2 = s|zdot^k, o3 = a|adot^k
         f32x4 e;
@@ -296,8 +315,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             out[t] = a.w0 * (o1[t] * acc[t] + (isv ? s1 : 0.f));
             e[t] = isv ? a.w0 * (o1[t] * sbar - sv * cbar) : -a.w0 * sv * chat;
         }
-        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.A, ub, lo, out);
-        DUDF_STB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo, e);
+        DUDF_STR(RL, (P24 & 1) != 0, a.A, ub, lo, out);
+        DUDF_STB((P24 & 2) != 0, a.E, ub, lo, e);
         if constexpr (TE) dudf_track(tk.e, e);
     } else if constexpr (SW == SWEEP_FWD_J) {
         const int lane = threadIdx.x & 63, l0 = lane & 48;
@@ -324,37 +343,37 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             const float st = quad_sum(isv ? 0.f : o2[t] * acc[t]);
             out[t] = o3[t] + a.w0 * o1[t] * acc[t] - (isv ? a.w0 * a.w0 * sv * st : 0.f);
         }
-        DUDF_STR(RL, P24 && (DUDF_P24_ARRAYS & 1), a.Z, ub, lo, out);
+        DUDF_STR(RL, (P24 & 1) != 0, a.Z, ub, lo, out);
     }
     if constexpr (amax_row<SW, FL>() >= 0) dudf_track(tk.t, out);
     return out;
 }
 
-template <int SW, int FL, bool P24 = false>
+template <int SW, int FL, int P24 = 0>
 __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, const LaneOff lo, f32x4& o1, f32x4& o2,
                                                f32x4& o3) {
     o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
     const unsigned vo = lo.v;
     if constexpr (SW == SWEEP_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 1), a.S, ub, lo);
+        if constexpr (FL & 1) o2 = DUDF_LDB((P24 & 1) != 0, a.S, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
         o1 = DUDF_LD(a.C, ub, vo);
-        o2 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo);
+        o2 = DUDF_LDB((P24 & 2) != 0, a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
         o1 = DUDF_LD(a.C, ub, vo);
-        if constexpr (FL & 1) o2 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo);      // no df/dx terms (loss_s2): e_l == 0
+        if constexpr (FL & 1) o2 = DUDF_LDB((P24 & 2) != 0, a.E, ub, lo);      // no df/dx terms (loss_s2): e_l == 0
     } else if constexpr (SW == SWEEP_REV_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
-        o3 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.R, ub, lo);
+        o3 = DUDF_LDB((P24 & 2) != 0, a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV_H) {
         o1 = DUDF_LD(a.C, ub, lo.c);
         o2 = DUDF_LD(a.ZS, ub, vo);
-        o3 = DUDF_LDB(P24 && (DUDF_P24_ARRAYS & 2), a.E, ub, lo);
+        o3 = DUDF_LDB((P24 & 2) != 0, a.E, ub, lo);
     }
 }
 

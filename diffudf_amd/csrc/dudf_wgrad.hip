@@ -1300,7 +1300,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     a.amax = reinterpret_cast<const unsigned*>(ws + lo.ws_amax);
     a.clk = dudf_prof_clk(PROF_WGRAD_HIDDEN);
     a.remap_nsplit = 0;
-    a.p24 = lo.p24 && (DUDF_P24_ARRAYS & 1);
+    a.p24 = lo.p24 & 1;
     const int hb = layer_begin < 1 ? 1 : layer_begin, he = layer_end > lo.L ? lo.L : layer_end;   // hidden matrices asked for
     a.j0 = hb - 1; a.nj = he > hb ? he - hb : 0;
     int rc = 0;
@@ -1326,7 +1326,7 @@ int dudf_launch_wgrad(const DudfLayout& lo, float* ws, float* dtheta, int have_g
     DudfProfScope prof(PROF_WGRAD_SMALL, st);
     const int fqn = lo.H / 4;                                              // feature quads; a block's 4 waves take one each per round:
     const int gy = fqn >= 64 ? 16 : (fqn >= 4 ? fqn / 4 : 1);              // up to 16 groups -> more loads in flight per CU
-    if (lo.p24 && (DUDF_P24_ARRAYS & 1)) {          // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
+    if (lo.p24 & 1) {                               // 24-bit tile-major arrays: one block row per feature tile, whole groups per block
         s.pts_per_block = (s.pts_per_block + 15) / 16 * 16;
         hipLaunchKernelGGL(wgrad_small_p24_kernel, dim3((unsigned)((lo.ncols + s.pts_per_block - 1) / s.pts_per_block), lo.H / 16),
                            dim3(dudf_deterministic() ? 64 : 256), 0, st, s);

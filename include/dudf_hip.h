@@ -222,12 +222,14 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
 int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, int64_t* out);
 
 /* Format of the stash a training workspace of this network keeps between the sweeps and the weight-gradient GEMM
- * (the activations `backward()` needs — what autograd saves for reference src/model.py:116-135 / src/diff_operators.py:208-212):
- *   0 = every array fp32, [layer][feature/4][column][4];
- *   1 = the arrays only the backward reads (S, Q, R, E, A, Z) hold fp32 values rounded to 24 bits (relative error <= 2^-17),
- *       12 bytes per 4 values, tile-major [layer][feature/16][column/16][64 lanes][3 dwords]; C and ZS stay fp32.
- * Selected per network by the library (DUDF_STASH=17|17p24; 24 bits need the fp16x3 kernels of 256-wide layers); -1 = bad cfg.
- * dudf_debug_read_stash decodes either. */
+ * (the activations `backward()` needs — what autograd saves for reference src/model.py:116-135 / src/diff_operators.py:208-212),
+ * as a bit mask of the arrays held as fp32 values rounded to 24 bits (relative error <= 2^-17), 12 bytes per 4 values,
+ * tile-major [layer][feature/16][column/16][64 lanes][3 dwords]:
+ *   bit 1 (2) = R, E — read only by the adjoint sweeps; bit 0 (1) = S, Q, A, Z — the weight-gradient GEMM's operands.
+ *   0 = every array fp32, [layer][feature/4][column][4]  (DUDF_STASH=17; every network that is not 256 wide);
+ *   2 = the default of 256-wide networks: every parity tolerance and the 12-step beetle trajectory hold unchanged;
+ *   3 = DUDF_STASH=17p24, opt-in: single-step tolerances hold, the beetle trajectory drifts to 4e-4 (tests/test_stash_p24_gpu.py).
+ * C and ZS are always fp32.  -1 = bad cfg.  dudf_debug_read_stash decodes every format. */
 int dudf_stash_mode(const dudf_net_cfg* cfg);
 
 /* One training batch on the GPU — replaces `sampleTrainingData` (reference src/dataset.py:14-70, open3d on the CPU)

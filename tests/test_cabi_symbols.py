@@ -36,8 +36,9 @@ def test_host_only_calls():
     assert lib.dudf_theta_count(ctypes.byref(cfg)) == 461825
     nb = lib.dudf_workspace_bytes(ctypes.byref(cfg), 29970)
     np_ = (29970 + 63) // 64 * 64
-    # seven stash arrays per layer and column: all fp32 (mode 0), or six of them at 3 bytes per value + C at 4 (mode 1)
-    per_value = {0: 7 * 4, 1: 6 * 3 + 4}[lib.dudf_stash_mode(ctypes.byref(cfg))]
+    # seven stash arrays per layer and column: all fp32 (mode 0), R and E at 3 bytes per value (mode 2, the default), or all six
+    # backward-only arrays at 3 bytes + C at 4 (mode 3)
+    per_value = {0: 7 * 4, 2: 5 * 4 + 2 * 3, 3: 6 * 3 + 4}[lib.dudf_stash_mode(ctypes.byref(cfg))]
     assert nb >= per_value * 8 * 256 * np_
     nbh = lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 29970, 9990)       # on-surface third on the Hessian path
     cols = (4 * 9990 + 63) // 64 * 64 + (19980 + 63) // 64 * 64

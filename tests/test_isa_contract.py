@@ -107,21 +107,27 @@ def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
             # strict (the other sweeps' operand waits, placed by the compiler, retire the older DMA pieces anyway)
             if key[0] == 0 and force == 0:
                 assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
-    # the builds that keep the backward-only stash arrays at 24 bits (training variants of the plain columns and of the quads):
-    # same step structure, dwordx3 stash accesses — the same replay must hold
-    for force in (0, 1):
-        res = analyse_f16(bf16_asm[f"late{force}"], family="f16p")
-        assert set(res) == {(0, 3), (1, 1), (2, 0), (3, 1), (3, 0), (4, 1), (5, 1), (6, 0), (7, 0)}, sorted(res)
-        for key, v in res.items():
-            assert len(v["waits"]) >= 8, (force, key, v["waits"])
-            for n, late, slack in v["waits"]:
-                assert late == 0, f"late={force} sweep_f16p_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) leaves {late} pieces of the next chunk in flight"
-    ship24 = analyse_f16(bf16_asm["ship"], family="f16p")
-    # (the opt-in 24-bit adjoint forward sweep sits at 256 registers and parks one value inside a k-block step: an extra
-    #  vector-memory operation there only makes the counted waits stricter; it is a cost, not a hazard, and one more reason
-    #  the 24-bit stash is not the default)
-    assert len(ship24) == 9 and all(v["scratch_hot"] <= 1 and v["scratch"] <= 12 for v in ship24.values()), \
-        {k: (v["scratch"], v["scratch_hot"]) for k, v in ship24.items()}
+    # the builds that keep stash arrays at 24 bits (training variants of the plain columns and of the quads) — f16r: R and E (the
+    # default stash of 256-wide networks), f16p: S, Q, A, Z as well (opt-in): same step structure, dwordx3 stash accesses — the
+    # same replay must hold
+    p24_keys = {(0, 3), (1, 1), (2, 0), (3, 1), (3, 0), (4, 1), (5, 1), (6, 0), (7, 0)}
+    for fam in ("f16r", "f16p"):
+        for force in (0, 1):
+            res = analyse_f16(bf16_asm[f"late{force}"], family=fam)
+            assert set(res) == p24_keys, (fam, sorted(res))
+            for key, v in res.items():
+                assert len(v["waits"]) >= 8, (fam, force, key, v["waits"])
+                for n, late, slack in v["waits"]:
+                    assert late == 0, f"late={force} sweep_{fam}_kernel<256,{key[0]},{key[1]}>: vmcnt({n}) leaves {late} pieces of the next chunk in flight"
+    # Nothing spills inside a k-block step — with ONE exception in both 24-bit families: the adjoint forward sweep (two 24-bit
+    # arrays: it unpacks R and packs E) sits at 256 registers and parks one value inside a step.  An extra vector-memory
+    # operation there only makes the counted waits stricter (a cost, not a hazard); measured, the sweep is still 10 % faster than
+    # its fp32-stash build (profiles/r04_p24_ab2.txt).
+    for fam in ("f16r", "f16p"):
+        ship = analyse_f16(bf16_asm["ship"], family=fam)
+        assert len(ship) == 9, (fam, sorted(ship))
+        for key, v in ship.items():
+            assert v["scratch_hot"] <= (1 if key == (2, 0) else 0) and v["scratch"] <= 20, (fam, key, v["scratch"], v["scratch_hot"])
     ship = analyse_f16(bf16_asm["ship"])                # the shipped kernels (both orders behind a wave-uniform branch): nothing spills inside a loop (a few dwords of cold address spills in the prologue are tolerated)
     assert len(ship) == 15 and all(v["scratch_hot"] == 0 and v["scratch"] <= 8 for v in ship.values()), \
         {k: (v["scratch"], v["scratch_hot"]) for k, v in ship.items()}
