@@ -25,7 +25,7 @@ NAMES = {"<256, 0, 3>": "sweep_fwd", "<256, 1, 1>": "sweep_rev", "<256, 2, 0>": 
 def kname(k):
     if "sweep_bf16_np_kernel" in k:
         k = k.replace("sweep_bf16_np_kernel", "sweep_bf16_kernel")      # the forward sweeps: build without packed fp32 ops
-    for f16 in ("sweep_f16p_np_kernel", "sweep_f16p_kernel", "sweep_f16_np_kernel", "sweep_f16_kernel"):   # the fp16x3 builds of the same sweeps (round 3); f16p: 24-bit stash (round 4)
+    for f16 in ("sweep_f16r_np_kernel", "sweep_f16r_kernel", "sweep_f16p_np_kernel", "sweep_f16p_kernel", "sweep_f16_np_kernel", "sweep_f16_kernel"):   # the fp16x3 builds of the same sweeps (round 3); f16p: 24-bit stash (round 4)
         if f16 in k:
             k = k.replace(f16, "sweep_bf16_kernel")
     for w in ("sweep_w16_kernel", "sweep_w_kernel"):                   # the 512-wide kernel: <SW, FL>
