@@ -10,8 +10,8 @@
     mode (terms 1e-5, d(theta) 1e-4 / 5e-4 with the Hessian term, stash columns 5e-5 / 2e-4) — the kernels are right;
   * the 12-step beetle trajectory does NOT hold the north star's 1e-4: Adam divides every gradient component by its own
     magnitude, so the components that sit at the noise floor flip sign, and a floor 128 times higher (2^-17 against fp32's
-    2^-24) moves the loss curve by 1e-4 .. 4e-4 within 12 steps (measured; fp32 stash: 7e-7).  That is why the default stays
-    fp32 — the test asserts the drift stays of that order so that the record in DESIGN.md §5d remains true.
+    2^-24) moves the loss curve by 1e-4 .. 4e-4 within 12 steps (measured; fp32 stash and mode 2: 3e-7).  That is why mode 3
+    stays opt-in — the test asserts the drift stays of that order so that the record in DESIGN.md §6 remains true.
 Each case runs in a child process: the stash format is chosen when the library first answers dudf_stash_mode."""
 import os
 import subprocess
