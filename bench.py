@@ -223,14 +223,15 @@ class Runner:
 
 
 # stash traffic of each kernel in BYTES per (layer, feature, column) — DESIGN.md §3.2 — for the stash formats (dudf_stash_mode):
-# 0 = every array fp32 (17 units); 2 = R and E at 24 bits = 3 bytes (16 units; the default); 3 = S, Q, A, Z as well (13.75).
+# 0 = every array fp32 (17 units); 6 = R, E as 24-bit floats and C as 24-bit fixed point = 3 bytes (15 units; the default);
+# 7 = S, Q, A, Z at 24 bits as well (12.75 units).
 #   forward: writes S, C | reverse: reads C, S, writes Q, R | adjoint forward: reads C, R, writes A, E |
 #   adjoint reverse: reads C, E, writes Z | weight gradients: read Q, A, Z, S.                  (bytes read, bytes written, layers)
 STASH_BYTES = {0: {"sweep_fwd": (0, 8, "L"), "sweep_rev": (8, 8, "L"), "sweep_adj_fwd": (8, 8, "L"), "sweep_adj_rev": (8, 4, "L"),
                    "wgrad_hidden": (16, 0, "L-1"), "wgrad_small": (16, 0, "1")},
-               2: {"sweep_fwd": (0, 8, "L"), "sweep_rev": (8, 7, "L"), "sweep_adj_fwd": (7, 7, "L"), "sweep_adj_rev": (7, 4, "L"),
+               6: {"sweep_fwd": (0, 7, "L"), "sweep_rev": (7, 7, "L"), "sweep_adj_fwd": (6, 7, "L"), "sweep_adj_rev": (6, 4, "L"),
                    "wgrad_hidden": (16, 0, "L-1"), "wgrad_small": (16, 0, "1")},
-               3: {"sweep_fwd": (0, 7, "L"), "sweep_rev": (7, 6, "L"), "sweep_adj_fwd": (7, 6, "L"), "sweep_adj_rev": (7, 3, "L"),
+               7: {"sweep_fwd": (0, 6, "L"), "sweep_rev": (6, 6, "L"), "sweep_adj_fwd": (6, 6, "L"), "sweep_adj_rev": (6, 3, "L"),
                    "wgrad_hidden": (12, 0, "L-1"), "wgrad_small": (12, 0, "1")}}
 SPLIT_BIT = {"sweep_fwd": 0, "sweep_rev": 1, "sweep_adj_fwd": 2, "sweep_adj_rev": 3, "wgrad_hidden": 4}
 
@@ -281,7 +282,7 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
     step_tf = 6 * F0 * n_cols / (ms_step * 1e-3) / 1e12
     traffic, step_hbm, source = None, None, None
     # PMC bytes exist for the two workloads this file reports: the headline and config 3
-    prof_json = os.path.join(REPO, "profiles", {(256, 100000): {0: "hbm_traffic_fp32.json", 2: "hbm_traffic.json", 3: "hbm_traffic_p24.json"}[stash_mode],
+    prof_json = os.path.join(REPO, "profiles", {(256, 100000): {0: "hbm_traffic_fp32.json", 6: "hbm_traffic.json", 7: "hbm_traffic_p24.json"}[stash_mode],
                                                 (512, 125000): "hbm_traffic_8x512.json"}.get((hidden, points), "-"))
     if os.path.exists(prof_json) and args.loss == "eikonal" and layers == 8:
         try:                                        # PMC bytes were collected on exactly this workload, see `source`
@@ -322,8 +323,8 @@ def roofline_block(args, info, hidden, layers, points, n_hess, ms_step):
     hbm_bound = d["hbm_frac"] >= d["frac"]
     out = {"kernel": dom, "mfma": d["mfma"], "clock_mhz": d["clock_mhz"], "traffic": traffic, "traffic_source": source,
            "stash": {0: "fp32 (17 array-layer units of 4 bytes per value and column)",
-                     2: "R and E at 24 bits (3 bytes per value, tile-major), the rest fp32: 16 units",
-                     3: "S, Q, R, E, A, Z at 24 bits (tile-major) + fp32 C: 13.75 units"}[stash_mode]}
+                     6: "R, E as 24-bit floats and C as 24-bit fixed point (3 bytes per value, tile-major), S, Q, A, Z fp32: 15 units",
+                     7: "S, Q, R, E, A, Z as 24-bit floats + C as 24-bit fixed point (tile-major): 12.75 units"}[stash_mode]}
     if hbm_bound:
         out.update({"bound": "hbm", "achieved": round(d["stash_tb_s"] * 1e3, 1), "peak": PEAK_HBM_TB_S * 1e3, "unit": "GB/s",
                     "frac": d["hbm_frac"], "algorithmic_bytes_per_launch": d["stash_bytes_per_launch"],

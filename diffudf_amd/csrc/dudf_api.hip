@@ -68,27 +68,28 @@ bool use_bf16_sweeps() {
 
 }  // namespace
 
-// DUDF_STASH (stash format of 256-wide training workspaces; dudf_stash_mode):
-//   "17"    = every array fp32: 17 array-layer units per column (rounds 1-3);
-//   "16"    = R and E at 24 bits, tile-major (dudf_internal.h): 16 units — the DEFAULT: every tolerance holds, the 12-step beetle
-//             trajectory included (3e-7), step -4 %;
-//   "17p24" = S, Q, A, Z as well (13.75 units, step -9 %): opt-in — every single-step tolerance holds, but 2^-17 noise on the
-//             weight-gradient GEMM's operands moves the beetle trajectory by 4e-4 (bar 1e-4; tests/test_stash_p24_gpu.py).
-// The 24-bit arrays exist in the fp16x3 training kernels of 256-wide networks (R, E) and in the cooperative-split
-// weight-gradient GEMM (S, Q, A, Z); an A/B switch that routes a kernel elsewhere drops the corresponding bit.
+// DUDF_STASH (stash format of 256-wide training workspaces; dudf_stash_mode returns the mask):
+//   "17"    = mask 0: every array fp32, 17 array-layer units per column (rounds 1-3);
+//   default = mask 6: R and E as 24-bit floats, C as 24-bit fixed point, tile-major (dudf_internal.h): 15 units.  Every tolerance
+//             holds, the 12-step beetle trajectory included (3e-7 .. 5e-7, as with fp32);
+//   "17p24" = mask 7: S, Q, A, Z as 24-bit floats as well (12.75 units): opt-in — every single-step tolerance holds, but 2^-17
+//             noise on the weight-gradient GEMM's operands moves the beetle trajectory by 4e-4 (bar 1e-4; tests/test_stash_p24_gpu.py).
+// The 24-bit arrays exist in the fp16x3 training kernels of 256- and 512-wide networks (R, E, C) and in the cooperative-split
+// weight-gradient GEMM of 256-wide ones (S, Q, A, Z); an A/B switch that routes a kernel elsewhere drops the corresponding bits.
 int dudf_stash_p24_enabled(int H, int L) {
     static const int want = [] {
         const char* e = getenv("DUDF_STASH");
-        int m = 2;
-        if (e && strstr(e, "p24")) m = 3;
+        int m = 6;
+        if (e && strstr(e, "p24")) m = 7;
         else if (e && strcmp(e, "17") == 0) m = 0;
-        else if (e && strcmp(e, "16") != 0) m = 2;
         if (!(use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47)) return 0;
         const char* w = getenv("DUDF_WGRAD");
-        if (w && w[0]) m &= 2;                                              // f32 / bf16w weight-gradient kernels read fp32 rows
+        if (w && w[0]) m &= 6;                                              // f32 / bf16w weight-gradient kernels read fp32 rows
         return m;
     }();
-    return (H == 256 && L >= 2 && L <= 32) ? want : 0;
+    if (H == 256 && L >= 2 && L <= 32) return want;
+    if (H == 512 && L >= 2) return want & 6;           // the 512-wide kernel relays S, Q, A, Z through the stash as fp32; R, E, C are not relays
+    return 0;
 }
 
 namespace {
@@ -151,7 +152,7 @@ int run_sweep(int base, const DudfLayout& lo, SweepArgs a, hipStream_t st) {
         a.tile0 = (int)(lo.ncol_h / DUDF_TILE_PTS); a.ntiles = (int)(lo.ncol_n / DUDF_TILE_PTS); a.hess = 0;
         rc = DUDF_E_UNSUPPORTED;
         if (use_bf16_sweeps() && dudf_sweep_bf16_handles(base, lo.H, lo.L, a)) rc = dudf_launch_sweep_bf16(base, lo.H, a, st);
-        if (rc == DUDF_E_UNSUPPORTED) {                           // width / variant without a 16-bit-core kernel (queries at H = 512)
+        if (rc == DUDF_E_UNSUPPORTED && !lo.p24) {                // width / variant without a 16-bit-core kernel (a 24-bit workspace has no other)
             if (base == SWEEP_FWD) a.store_s = a.store_c = 1;     // the f32 kernel only builds its stash-everything variant
             rc = dudf_launch_sweep(base, lo.H, a, st);
         }
@@ -624,8 +625,8 @@ int dudf_debug_read_stash(const dudf_net_cfg* cfg, int which, int layer, int cha
     const DudfLayout& lo = c.lo;
     const int64_t offs[8] = {lo.ws_S, lo.ws_C, lo.ws_Q, lo.ws_E, lo.ws_A, lo.ws_Z, lo.ws_R, lo.ws_ZS};
     if (which < 0 || which > 7) return DUDF_E_BADMODE;
-    // S, Q, A, Z (bit 0) | E, R (bit 1): 24-bit tile-major
-    const bool b24 = which != 1 && which != 7 && (lo.p24 & ((which == 3 || which == 6) ? 2 : 1)) != 0;
+    // S, Q, A, Z (bit 0) | E, R (bit 1): 24-bit floats, tile-major; C (bit 2): 24-bit fixed point, same granules
+    const int b24 = which == 7 ? 0 : which == 1 ? ((lo.p24 & 4) ? 2 : 0) : (lo.p24 & ((which == 3 || which == 6) ? 2 : 1)) ? 1 : 0;
     return dudf_launch_read_stash(lo, c.ws + offs[which], layer, channel, out, c.st, which == 1, b24);   // C: one copy per quad
 }
 

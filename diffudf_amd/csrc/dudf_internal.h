@@ -52,7 +52,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // "p24" stash (round 4; DudfLayout::p24, training workspaces of 256-wide networks whose sweeps and weight-gradient GEMM run
 // their fp16x3 kernels; DUDF_STASH=17 keeps everything fp32): the arrays that only the BACKWARD reads — S, Q, R, E, A, Z —
 // hold fp32 values rounded to 24 bits (sign, 8 exponent, 15 mantissa bits: relative error <= 2^-17), four values in 12
-// bytes; C (read by the reverse sweep, whose df/dx has no precision to spare) and ZS stay fp32.  A 12-byte granule per
+// bytes; ZS stays fp32; C (read by the reverse sweep, whose df/dx has no precision to spare) cannot take a 2^-17 relative error
+// either, but |cos| <= 1 needs no exponent: bit 2 of the mask stores it as 24-bit FIXED POINT on a 2^-22 grid (absolute error
+// <= 2^-23, the size of the sin/cos polynomials' own error; dudf_sweep_common.h c24_pack) in the same granules.  A 12-byte granule per
 // lane makes 192-byte row segments, every second cache line shared by two waves: measured, partial-line writes give back
 // 15 of the 25 % (tools/micro/hbm_p24.hip, profiles/r04_hbm_p24.txt).  So these arrays are TILE-MAJOR instead:
 //     [layer][feature tile T = f/16][column group g = p/16][lane = 16*((f%16)/4) + p%16][3 dwords]
@@ -60,10 +62,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //     byte offset of granule (layer, f, p) = (((layer*(H/16) + f/16)*(np/16) + p/16)*64 + 16*((f%16)/4) + p%16)*12
 // dwords of a granule (values v0..v3 = features 4q..4q+3, u_i = bits(v_i) + 0x80):
 //     d0 = u0>>8 | u1.byte1<<24,  d1 = u1>>16 | (u2>>8)<<16,  d2 = u2.byte3 | (u3>>8)<<8
+// C: u_i = the low 24 bits of bits(c_i + 3.0f) = (c_i + 1) 2^22;  d_i = u_i | u3.byte_i << 24  (i = 0, 1, 2).  In the Hessian-quad columns C keeps one granule per quad: `p` above is then the quad's index p >> 2
+// (groups [0, ncol_h/64), below the plain columns' groups, which start at ncol_h/16).
 struct DudfLayout {
     int H, L;
     float rho;               // w0 / ww (dudf_net_cfg): the first layer is packed times rho, `w0` below is the ONE frequency the kernels run (ww)
-    int p24;                 // which arrays are 24-bit tile-major (see above): bit 0 = S, Q, A, Z (the weight-gradient GEMM's operands), bit 1 = R, E
+    int p24;                 // which arrays are 24-bit tile-major (see above): bit 0 = S, Q, A, Z (the weight-gradient GEMM's operands), bit 1 = R, E, bit 2 = C (fixed point)
     float w0;
     int64_t n, n_h;          // points, and how many of them (the first n_h) take the Hessian path
     int64_t ncol_h, ncol_n;  // padded column counts of the two ranges
@@ -80,7 +84,7 @@ struct DudfLayout {
 
 // 24-bit stash selected for this network?  (dudf_api.hip: DUDF_STASH, and every kernel of the step must be the fp16x3 build
 // that reads / writes it)
-int dudf_stash_p24_enabled(int H, int L);   // the mask (0, 2 or 3)
+int dudf_stash_p24_enabled(int H, int L);   // the mask (0, 6 or 7)
 
 static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_h, DudfLayout* lo, int query_only = 0) {
     if (!cfg || cfg->n_in != 3 || cfg->n_hidden_layers < 1) return DUDF_E_BADCFG;
@@ -133,7 +137,8 @@ static inline int dudf_make_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n
     const int64_t stash = (int64_t)L * lo->stash_layer;
     const int64_t stash_b = (lo->p24 & 1) ? stash / 4 * 3 : stash;   // S, Q, A, Z: 12 instead of 16 bytes per granule
     const int64_t stash_r = (lo->p24 & 2) ? stash / 4 * 3 : stash;   // R, E
-    lo->ws_S = take(stash_b); lo->ws_C = take(stash);
+    const int64_t stash_c = (lo->p24 & 4) ? stash / 4 * 3 : stash;   // C (fixed point)
+    lo->ws_S = take(stash_b); lo->ws_C = take(stash_c);
     lo->ws_ZS = n_h > 0 ? take(stash) : lo->ws_S;
     if (query_only) {        // value / df/dx / Hessian queries only ever touch S, C, ZS: 16-24 KB per column instead of 56-64
         lo->ws_Q = lo->ws_R = lo->ws_E = lo->ws_A = lo->ws_Z = lo->ws_S;
@@ -178,7 +183,7 @@ struct SweepArgs {
     int L; float w0;
     int store_s, store_c, train;   // what the sweep has to leave behind
     int have_e;                    // reverse adjoint sweep: e_l was produced by SWEEP_ADJ_FWD
-    int p24;                       // which stash arrays are 24-bit tile-major (DudfLayout::p24: bit 0 = S, Q, A, Z, bit 1 = R, E)
+    int p24;                       // which stash arrays are 24-bit tile-major (DudfLayout::p24: bit 0 = S, Q, A, Z, bit 1 = R, E, bit 2 = C)
 };
 
 enum { SWEEP_FWD = 0, SWEEP_REV = 1, SWEEP_ADJ_FWD = 2, SWEEP_ADJ_REV = 3,

@@ -389,8 +389,14 @@ __global__ __launch_bounds__(256) void read_stash_kernel(const float* __restrict
                                 ((((int64_t)(f >> 4) * (np >> 4) + (c >> 4)) * 64) + 16 * ((f & 15) >> 2) + (c & 15)) * 3;
             const unsigned d0 = g[0], d1 = g[1], d2 = g[2];
             const int e = f & 3;
-            const unsigned u = e == 0 ? d0 << 8 : e == 1 ? ((d0 >> 24) << 8) | (d1 << 16) : e == 2 ? ((d1 >> 16) << 8) | (d2 << 24) : d2 & 0xffffff00u;
-            out[i] = __uint_as_float(u);
+            if (p24 == 2) {                                  // C: fixed point — the low 24 bits of bits(c + 3.0f) (c24_pack)
+                const unsigned u = e == 0 ? d0 & 0xffffffu : e == 1 ? d1 & 0xffffffu : e == 2 ? d2 & 0xffffffu
+                                                                  : (d0 >> 24) | ((d1 >> 24) << 8) | ((d2 >> 24) << 16);
+                out[i] = __uint_as_float(0x40000000u | u) - 3.0f;
+            } else {
+                const unsigned u = e == 0 ? d0 << 8 : e == 1 ? ((d0 >> 24) << 8) | (d1 << 16) : e == 2 ? ((d1 >> 16) << 8) | (d2 << 24) : d2 & 0xffffff00u;
+                out[i] = __uint_as_float(u);
+            }
         } else {
             out[i] = src[((int64_t)(f >> 2) * np + c) * 4 + (f & 3)];
         }

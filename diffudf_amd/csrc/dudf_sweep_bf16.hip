@@ -225,7 +225,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     using G = GeoB<H, SP>;
     constexpr int NPC = G::NPC;
     static_assert(SP == 0 || SW <= SWEEP_FWD_J, "fp16x3: plain columns, Hessian quads, jets");
-    static_assert(P24 == 0 || ((P24 == 2 || P24 == 3) && SP != 0 && H == 256 && !is_jet(SW)), "24-bit stash arrays (mask 2: R, E; 3: all six): the fp16x3 training kernels of 256-wide layers");
+    static_assert(P24 == 0 || ((P24 == 6 || P24 == 7) && SP != 0 && H == 256 && !is_jet(SW)), "24-bit stash arrays (mask 6: R, E, C; 7: S, Q, A, Z as well): the fp16x3 training kernels of 256-wide layers");
     constexpr int BS = base_of(SW);
     constexpr bool HS = is_hess(SW);                   // quads: lane & 3 = channel (0 = value, 1 + k = tangent d/dx_k); jets:
                                                        // lane & 15 = Taylor monomial (0 = value), see dudf_sweep_common.h
@@ -346,7 +346,9 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
     };
     const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);     // this lane's granule, in bytes
     const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo,   // C: one copy per quad
-                     P24 ? (unsigned)(((p >> 4) * 64 + lane) * 12) : 0u);                                         // 24-bit tile-major arrays
+                     P24 ? (unsigned)(((p >> 4) * 64 + lane) * 12) : 0u,                                          // 24-bit tile-major arrays
+                     !P24 ? 0u : (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((p >> 6) * 64 + 16 * q + ((p >> 2) & 15)) * 12)   // C there: column p >> 2 of the quad region
+                                                              : (unsigned)(((p >> 4) * 64 + lane) * 12));
     auto load_ops = [&](int layer, int kb, TailOps& o) {
         epilogue_loads<SW, FL, P24>(a, stash_base(layer, 2 * kb), vl, o.o1a, o.o2a, o.o3a);
         epilogue_loads<SW, FL, P24>(a, stash_base(layer, 2 * kb + 1), vl, o.o1b, o.o2b, o.o3b);
@@ -970,15 +972,15 @@ __global__ __launch_bounds__(64 * NWB) void sweep_f16_kernel(SweepArgs a) { swee
 template <int H, int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1>(a, blockIdx.x, gridDim.x); }
 // ... and the fp16x3 builds that keep stash arrays at 24 bits, tile-major (dudf_internal.h "p24"; training variants):
-// f16r: R and E (mask 2, the default stash of 256-wide networks); f16p: S, Q, A, Z as well (mask 3, DUDF_STASH=17p24)
+// f16r: R, E and C (mask 6, the default stash of 256-wide networks); f16p: S, Q, A, Z as well (mask 7, DUDF_STASH=17p24)
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_f16r_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 2>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64 * NWB) void sweep_f16r_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 6>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16r_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 2>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16r_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 6>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) void sweep_f16p_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 3>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64 * NWB) void sweep_f16p_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 7>(a, blockIdx.x, gridDim.x); }
 template <int H, int SW, int FL>
-__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16p_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 3>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64 * NWB) DUDF_NO_PK void sweep_f16p_np_kernel(SweepArgs a) { sweep_body_b<H, SW, FL, 1, 7>(a, blockIdx.x, gridDim.x); }
 // Pair launch (a batch with Hessian-path points: `loss_s1` with its eigenvector term, the reference's shipped recipe).  A sweep
 // then has two column ranges — the quads (variant SWQ; fp16x3 or, SPQ = 0, bf16x6) and the plain columns (fp16x3, variant SWP) — which used to be
 // two launches of <= 256 persistent workgroups each: at the reference's batch (29 970 points = 312 + 156 tiles of 128 columns)
@@ -1214,11 +1216,13 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         do {                                                                                                    \
             bool p_ = false;                                                                                    \
             if constexpr (H == 256) {                                                                           \
-                if (a.p24 == 3) { DUDF_GO_H(SW, FL, KERNELP, SMEM_MAX, SMEM); p_ = true; }                      \
-                else if (a.p24 == 2) { DUDF_GO_H(SW, FL, KERNELR, SMEM_MAX, SMEM); p_ = true; }                 \
+                if (a.p24 == 7) { DUDF_GO_H(SW, FL, KERNELP, SMEM_MAX, SMEM); p_ = true; }                      \
+                else if (a.p24 == 6) { DUDF_GO_H(SW, FL, KERNELR, SMEM_MAX, SMEM); p_ = true; }                 \
             }                                                                                                   \
             if (!p_) { if (a.p24) return DUDF_E_UNSUPPORTED; DUDF_GO_H(SW, FL, KERNEL, SMEM_MAX, SMEM); }       \
         } while (0)
+        // (a 24-bit workspace holds C as fixed point: only the training variants, which are built for it, may touch it)
+        if (a.p24 && ((which == SWEEP_FWD && !(a.store_s && a.store_c)) || (which == SWEEP_REV && !a.train))) return DUDF_E_UNSUPPORTED;
         if (which == SWEEP_FWD && a.L <= kMaxLdsBiasLayers) {
             if (a.store_s && a.store_c) DUDF_GO_HP(SWEEP_FWD, 3, DUDF_FWD_F16_KERNEL, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_fmax, smem_f);
             else if (a.store_c) DUDF_GO_H(SWEEP_FWD, 2, DUDF_FWD_F16_KERNEL, smem_fmax, smem_f);
@@ -1244,6 +1248,7 @@ int launch_b(int which, const SweepArgs& a, hipStream_t st) {
         const size_t smem_fq = w3 + (size_t)a.L * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         constexpr size_t smem_fqmax = w3 + kMaxLdsBiasLayers * H * sizeof(float) + kMaxAmaxLayers * sizeof(unsigned);
         bool done = true;
+        if (a.p24 && ((which == SWEEP_FWD_H && !a.store_s) || (which == SWEEP_REV_H && !a.train))) return DUDF_E_UNSUPPORTED;
         if (which == SWEEP_FWD_H) { if (a.store_s) DUDF_GO_HP(SWEEP_FWD_H, 1, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_fqmax, smem_fq); else DUDF_GO_H(SWEEP_FWD_H, 0, sweep_f16_np_kernel, smem_fqmax, smem_fq); }
         else if (which == SWEEP_REV_H) { if (a.train) DUDF_GO_HP(SWEEP_REV_H, 1, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q); else DUDF_GO_H(SWEEP_REV_H, 0, sweep_f16_np_kernel, smem_q, smem_q); }
         else if (which == SWEEP_ADJ_FWD_H && a.ebound) DUDF_GO_HP(SWEEP_ADJ_FWD_H, 0, sweep_f16_np_kernel, sweep_f16r_np_kernel, sweep_f16p_np_kernel, smem_q, smem_q);
@@ -1337,8 +1342,10 @@ using GeoW = GeoWT<0>;
 
 // SP = 1: fp16x3 (see GeoB).  The B operand of a layer is read back from the stash AFTER the whole previous layer has been
 // written, so its per-column scale is exact here: 2^15 over the column's largest |output| of the tail burst.
-template <int SW, int FL, int SP = 0>
+// P24 (0 or 6): R, E as 24-bit floats and C as 24-bit fixed point, tile-major (dudf_internal.h) — the arrays that are NOT the relay.
+template <int SW, int FL, int SP = 0, int P24 = 0>
 __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_first, const int nact, char* lds, unsigned& gc) {
+    static_assert(P24 == 0 || (P24 == 6 && SP != 0 && !is_jet(SW)), "24-bit stash arrays in the 512-wide kernel: R, E, C of the fp16x3 training variants");
     using G = GeoWT<SP>;
     constexpr int H = G::H;
     constexpr int NPC = G::NPC;
@@ -1368,7 +1375,10 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
     const unsigned vo = (unsigned)(((int64_t)q * a.np + p) * 16);
-    const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo);   // C: one copy per quad
+    const LaneOff vl(vo, (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((int64_t)q * a.np + (p >> 2)) * 16) : vo,   // C: one copy per quad
+                     P24 ? (unsigned)(((p >> 4) * 64 + lane) * 12) : 0u,                                          // 24-bit tile-major arrays
+                     !P24 ? 0u : (is_hess(SW) && !is_jet(SW)) ? (unsigned)(((p >> 6) * 64 + 16 * q + ((p >> 2) & 15)) * 12)
+                                                              : (unsigned)(((p >> 4) * 64 + lane) * 12));
     const int total2 = nhid * G::NKB * 2;
     auto chunk_src = [&](int c2) -> const char* {       // c2 = (matrix, k-block, half), wave-uniform
         const int j = c2 / (G::NKB * 2);
@@ -1415,7 +1425,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         constexpr int PD = (BS == SWEEP_FWD) ? 2 : ((SW == SWEEP_ADJ_FWD_H || SW == SWEEP_ADJ_REV_H) ? 4 : 8);
         f32x4 o1[PD], o2[PD], o3[PD], bs[PD];
         auto ld = [&](int T, int s) {
-            epilogue_loads<SW, FL>(a, stash_base(layer, T), vl, o1[s], o2[s], o3[s]);
+            epilogue_loads<SW, FL, P24>(a, stash_base(layer, T), vl, o1[s], o2[s], o3[s]);
             if constexpr (BS == SWEEP_FWD) bs[s] = *reinterpret_cast<const f32x4*>(bias_ptr(layer) + 16 * T + 4 * q);
         };
         float cmax = 0.f;                              // fp16x3: largest |output| of this lane's rows of the column
@@ -1431,7 +1441,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             else if constexpr (BS == SWEEP_FWD) z = (SP != 0 ? z * unscale : z) + (isv ? bs[s] : zero4);   // the bias: value channel only
             else if constexpr (SP != 0) z *= unscale;
             // (RL: the array the next layer reads its operand back from keeps the default cache policy — DUDF_W_RELAY_NT=1: A/B)
-            const f32x4 e = epilogue<SW, FL, false, false, !DUDF_W_RELAY_NT>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
+            const f32x4 e = epilogue<SW, FL, false, P24, !DUDF_W_RELAY_NT>(a, z, o1[s], o2[s], o3[s], stash_base(layer, T), vl, isv, tmax);
             if constexpr (wide_relay_store<SW, FL>()) { if constexpr (DUDF_W_RELAY_NT) DUDF_ST(a.S, stash_base(layer, T), vo, e); else DUDF_ST_CACHED(a.S, stash_base(layer, T), vo, e); }
             if constexpr (kColScale) dudf_track(cmax, e);
             if (T + PD < G::NT) ld(T + PD, s);
@@ -1596,7 +1606,7 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
     }
 }
 
-template <int SW, int FL, int SP>
+template <int SW, int FL, int SP, int P24 = 0>
 __device__ __forceinline__ void sweep_w_body(const SweepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char lds_w[];
     unsigned gc = 0;
@@ -1610,7 +1620,7 @@ __device__ __forceinline__ void sweep_w_body(const SweepArgs& a) {
     const int ng = a.ntiles * (TILE / 16), gbase = a.tile0 * (TILE / 16);
     const int g0 = (int)((int64_t)blockIdx.x * ng / gridDim.x), g1 = (int)((int64_t)(blockIdx.x + 1) * ng / gridDim.x);
     for (int g = g0; g < g1; g += NWB)
-        sweep_tile_w<SW, FL, SP>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_w, gc);
+        sweep_tile_w<SW, FL, SP, P24>(a, gbase + g, (g1 - g < NWB) ? g1 - g : NWB, lds_w, gc);
     if constexpr (kRow >= 0) {
         __syncthreads();
         if ((int)threadIdx.x < a.L && (int)threadIdx.x < kMaxAmaxLayers && a.amax) {
@@ -1627,6 +1637,9 @@ template <int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_w_kernel(SweepArgs a) { sweep_w_body<SW, FL, 0>(a); }
 template <int SW, int FL>
 __global__ __launch_bounds__(64 * NWB) void sweep_w16_kernel(SweepArgs a) { sweep_w_body<SW, FL, 1>(a); }
+// ... with R, E, C at 24 bits (stash mask 6: the training variants of a default training workspace)
+template <int SW, int FL>
+__global__ __launch_bounds__(64 * NWB) void sweep_w16r_kernel(SweepArgs a) { sweep_w_body<SW, FL, 1, 6>(a); }
 
 int launch_w(int which, const SweepArgs& a, hipStream_t st) {
     using G = GeoW;
@@ -1660,8 +1673,36 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
         }                                                                                                   \
         hipLaunchKernelGGL((sweep_w16_kernel<SW, FL>), dim3(grid), dim3(G::NTHR), smem16, st, a);           \
     } while (0)
-    // fp16x3 or bf16x6: plain columns by their DUDF_SPLIT_SWEEPS bit, quads and jets by bit 5 (DUDF_SPLIT_QUADS)
+#define DUDF_GO_W16R(SW, FL)                                                                                \
+    do {                                                                                                    \
+        if (SW <= SWEEP_ADJ_REV) dudf_note_products(PROF_SWEEP_FWD + SW, 3);                                \
+        static bool attr_done = false;                                                                      \
+        const size_t smem16 = 3 * GeoWT<1>::CHUNKB + kMaxAmaxLayers * sizeof(unsigned);                     \
+        if (!attr_done) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_w16r_kernel<SW, FL>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);               \
+            if (e != hipSuccess) return (int)e;                                                             \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((sweep_w16r_kernel<SW, FL>), dim3(grid), dim3(G::NTHR), smem16, st, a);          \
+    } while (0)
+    // fp16x3 or bf16x6: plain columns by their bit of the split mask, quads and jets by bit 5 (DUDF_SPLIT_QUADS)
     const bool h16 = which <= SWEEP_ADJ_REV ? ((a.split >> which) & 1) != 0 : (a.split & 32) != 0;
+    if (a.p24) {                                     // a training workspace with R, E, C at 24 bits: its training variants only
+        if (a.p24 != 6 || !h16) return DUDF_E_UNSUPPORTED;
+        switch (which) {
+            case SWEEP_FWD: if (a.store_s && a.store_c) DUDF_GO_W16R(SWEEP_FWD, 3); else return DUDF_E_UNSUPPORTED; break;
+            case SWEEP_REV: if (a.train) DUDF_GO_W16R(SWEEP_REV, 1); else return DUDF_E_UNSUPPORTED; break;
+            case SWEEP_ADJ_FWD: DUDF_GO_W16R(SWEEP_ADJ_FWD, 0); break;
+            case SWEEP_ADJ_REV: if (a.have_e) DUDF_GO_W16R(SWEEP_ADJ_REV, 1); else DUDF_GO_W16R(SWEEP_ADJ_REV, 0); break;
+            case SWEEP_FWD_H: if (a.store_s) DUDF_GO_W16R(SWEEP_FWD_H, 1); else return DUDF_E_UNSUPPORTED; break;
+            case SWEEP_REV_H: if (a.train) DUDF_GO_W16R(SWEEP_REV_H, 1); else return DUDF_E_UNSUPPORTED; break;
+            case SWEEP_ADJ_FWD_H: DUDF_GO_W16R(SWEEP_ADJ_FWD_H, 0); break;
+            case SWEEP_ADJ_REV_H: DUDF_GO_W16R(SWEEP_ADJ_REV_H, 0); break;
+            default: return DUDF_E_UNSUPPORTED;
+        }
+        return (int)hipGetLastError();
+    }
 #define DUDF_W(SW, FL) do { if (h16) DUDF_GO_W16(SW, FL); else DUDF_GO_W(SW, FL); } while (0)
     // The stash array a layer's outputs travel through is written in every variant (wide_in): the forward sweeps always
     // store h_l (a value-only query: nothing else), the query variants of the reverse sweeps park q_l in S.
@@ -1679,6 +1720,7 @@ int launch_w(int which, const SweepArgs& a, hipStream_t st) {
     }
 #undef DUDF_W
 #undef DUDF_GO_W16
+#undef DUDF_GO_W16R
 #undef DUDF_GO_W
     return (int)hipGetLastError();
 }
@@ -1760,18 +1802,19 @@ int dudf_launch_sweep_pair(int base, int H, const SweepArgs& aq0, const SweepArg
     const size_t sq = q16 ? w3 + (base == SWEEP_FWD ? (size_t)aq.L * 256 * sizeof(float) : 0) + kMaxAmaxLayers * sizeof(unsigned) : kPairSmemQ;
     const size_t smem = sq > sp ? sq : sp;
     if (ap.p24 != aq.p24 || (ap.p24 && !q16)) return DUDF_E_UNSUPPORTED;   // (the 24-bit stash needs the quads on fp16x3 too: dudf_stash_p24_enabled)
-    if (ap.p24 == 3) switch (base) {
-        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 3>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 3>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 3>(aq, ap, smem, nbq, nbp, st);
-        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 3>(aq, ap, smem, nbq, nbp, st);
+    if (ap.p24 == 7) switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 7>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 7>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 7>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 7>(aq, ap, smem, nbq, nbp, st);
     }
-    if (ap.p24 == 2) switch (base) {
-        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 2>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 2>(aq, ap, smem, nbq, nbp, st);
-        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 2>(aq, ap, smem, nbq, nbp, st);
-        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 2>(aq, ap, smem, nbq, nbp, st);
+    if (ap.p24 == 6) switch (base) {
+        case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1, 6>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1, 6>(aq, ap, smem, nbq, nbp, st);
+        case SWEEP_ADJ_FWD: return launch_pair_t<SWEEP_ADJ_FWD_H, 0, SWEEP_ADJ_FWD, 0, 1, 6>(aq, ap, smem, nbq, nbp, st);
+        default: return launch_pair_t<SWEEP_ADJ_REV_H, 0, SWEEP_ADJ_REV, 1, 1, 6>(aq, ap, smem, nbq, nbp, st);
     }
+    if (ap.p24) return DUDF_E_UNSUPPORTED;
     if (q16) switch (base) {
         case SWEEP_FWD: return launch_pair_t<SWEEP_FWD_H, 1, SWEEP_FWD, 3, 1>(aq, ap, smem, nbq, nbp, st);
         case SWEEP_REV: return launch_pair_t<SWEEP_REV_H, 1, SWEEP_REV, 1, 1>(aq, ap, smem, nbq, nbp, st);

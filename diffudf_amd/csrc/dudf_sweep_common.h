@@ -133,11 +133,44 @@ __device__ __forceinline__ f32x4 dudf_raw3(const dudf_u3 d) { return f32x4{__uin
 #define DUDF_LD24RAW(arr, ub, vt) dudf_raw3(__builtin_nontemporal_load(DUDF_CAT24(arr, ub, vt)))
 #endif
 __device__ __forceinline__ f32x4 p24_unpack_raw(const f32x4 r) { return p24_unpack(dudf_u3{__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2])}); }
+// ---- C = cos(w0 z_l) as 24-bit FIXED POINT (DudfLayout::p24 bit 2; same tile-major granules) ------------------------------------
+// |c| <= 1 needs no exponent: t = c + 3 lies in [2, 4], one binade, so the float add itself rounds c to nearest on a 2^-22 grid
+// and the low 24 bits of t's pattern are the unsigned integer (c + 1) 2^22 in [0, 2^23] (t = 4 carries into the exponent's low
+// bit, which is bit 23: still the right integer).  One v_add_f32 per value to write; to read, the top byte 0x40 comes back
+// (t's patterns are 0x40000000 | u) and c = t - 3 is exact.  Absolute error <= 2^-23 = 1.2e-7 — the size of the polynomial
+// pair's own error (9.4e-8) — where a 24-bit FLOAT (the "p24" arrays) would lose 2^-17 of every value; the 12-step beetle
+// trajectory does not see it (profiles/r04_cround.txt: 2^-22 and 2^-23 grids both within 5e-7, like fp32).
+__device__ __forceinline__ dudf_u3 c24_pack(const f32x4 c) {
+    const unsigned u0 = __float_as_uint(c[0] + 3.0f), u1 = __float_as_uint(c[1] + 3.0f),
+                   u2 = __float_as_uint(c[2] + 3.0f), u3 = __float_as_uint(c[3] + 3.0f);
+    // values 0-2 in the low three bytes of a dword each, value 3 spread over the three top bytes: three of four values come back
+    // with one bit-field insert, and the read side needs three constants instead of six.  (Packed back to back like the 24-bit
+    // floats, the reverse sweep — at 256 registers — reloaded two spilled constants in every k-block step.)
+    dudf_u3 d;
+    d.x = __builtin_amdgcn_perm(u3, u0, 0x04020100u);
+    d.y = __builtin_amdgcn_perm(u3, u1, 0x05020100u);
+    d.z = __builtin_amdgcn_perm(u3, u2, 0x06020100u);
+    return d;
+}
+__device__ __forceinline__ f32x4 c24_unpack(const dudf_u3 d) {
+    const unsigned m = 0x00ffffffu, two = 0x40000000u;          // (the pattern of 2.0f: an inline constant)
+    const unsigned t0 = (d.x & m) | two, t1 = (d.y & m) | two, t2 = (d.z & m) | two;     // v_and_or_b32
+    const unsigned y = __builtin_amdgcn_perm(d.y, d.x, 0x0c0c0703u);                    // [d0.b3, d1.b3, 0, 0]
+    const unsigned t3 = __builtin_amdgcn_perm(d.z, y, 0x0c070100u) | two;               // [.., .., d2.b3, 0] | 0x40 on top
+    return f32x4{__uint_as_float(t0) - 3.0f, __uint_as_float(t1) - 3.0f, __uint_as_float(t2) - 3.0f, __uint_as_float(t3) - 3.0f};
+}
+__device__ __forceinline__ f32x4 c24_unpack_raw(const f32x4 r) { return c24_unpack(dudf_u3{__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2])}); }
+#if DUDF_SWEEP_DBG & 1
+#define DUDF_STC24(arr, ub, vt, val) asm volatile("" :: "v"(c24_pack((f32x4)(val))))
+#else
+#define DUDF_STC24(arr, ub, vt, val) __builtin_nontemporal_store(c24_pack((f32x4)(val)), DUDF_AT24(arr, ub, vt))
+#endif
 // a backward-only array in the format of this build: P (compile-time) = 24-bit tile-major, else fp32 rows
 #define DUDF_STB(P, arr, ub, lo, val) do { if constexpr (P) DUDF_ST24(arr, ub, (lo).t, val); else DUDF_ST(arr, ub, (lo).v, val); } while (0)
 // ... or, RL (compile-time): this array is the caller's relay — default cache policy
 #define DUDF_STR(RL, P, arr, ub, lo, val) do { if constexpr (RL) DUDF_ST_CACHED(arr, ub, (lo).v, val); else DUDF_STB(P, arr, ub, lo, val); } while (0)
 #define DUDF_LDB(P, arr, ub, lo) ((P) ? DUDF_LD24RAW(arr, ub, (lo).t) : DUDF_LD(arr, ub, (lo).v))     // (P: raw, unpacked by epilogue())
+#define DUDF_LDC(P, arr, ub, lo) ((P) ? DUDF_LD24RAW(arr, ub, (lo).ct) : DUDF_LD(arr, ub, (lo).c))    // C (fixed point when P; `c` == `v` in plain columns)
 
 // ---- quad (4 adjacent lanes = the 4 channels of one Hessian-path point) helpers: DPP, no LDS -------------
 // (the empty asm pins the DPP source to an ARCHITECTURAL vector register: in the 512-register kernels of the 512-wide
@@ -231,21 +264,24 @@ __device__ __forceinline__ void dudf_track(float& tmax, const f32x4 v) {
 // (p >> 2) of the quad region, written and read by all four lanes (same bits, same granule: one 16-byte access serves four lanes) —
 // instead of four: 3 of the quad sweeps' 16 stash units per column gone.
 // `t`: the lane's byte offset inside a (layer, tile) block of a 24-bit tile-major array (0 where the build has none).
+// `ct`: the same for C (its own: one granule per quad in the Hessian-quad columns, like `c`).
 struct LaneOff {
-    unsigned v, c, t;
-    __device__ __forceinline__ LaneOff(unsigned x) : v(x), c(x), t(0) {}
-    __device__ __forceinline__ LaneOff(unsigned x, unsigned y) : v(x), c(y), t(0) {}
-    __device__ __forceinline__ LaneOff(unsigned x, unsigned y, unsigned z) : v(x), c(y), t(z) {}
+    unsigned v, c, t, ct;
+    __device__ __forceinline__ LaneOff(unsigned x) : v(x), c(x), t(0), ct(0) {}
+    __device__ __forceinline__ LaneOff(unsigned x, unsigned y) : v(x), c(y), t(0), ct(0) {}
+    __device__ __forceinline__ LaneOff(unsigned x, unsigned y, unsigned z) : v(x), c(y), t(z), ct(z) {}
+    __device__ __forceinline__ LaneOff(unsigned x, unsigned y, unsigned z, unsigned w) : v(x), c(y), t(z), ct(w) {}
 };
 
 // RL: the array that carries this sweep's post-tail values (S / Q / A / Z by sweep) is stored with the default cache policy
-// P24: which arrays are 24-bit tile-major in this build (DudfLayout::p24): bit 0 = S, Q, A, Z; bit 1 = R, E
+// P24: which arrays are 24-bit tile-major in this build (DudfLayout::p24): bit 0 = S, Q, A, Z; bit 1 = R, E; bit 2 = C (fixed point)
 template <int SW, int FL, bool TE = false, int P24 = 0, bool RL = false>
 __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o1, f32x4 o2, f32x4 o3, int64_t ub,
                                           const LaneOff lo, bool isv, TailTrack& tk) {
     const unsigned vo = lo.v;
     // operands that arrive as raw 24-bit granules (epilogue_loads): S in the reverse sweep, R in the adjoint forward sweeps,
     // E in the adjoint reverse sweeps
+    if constexpr ((P24 & 4) != 0 && base_of(SW) != SWEEP_FWD) o1 = c24_unpack_raw(o1);      // C: every sweep behind the forward one
     if constexpr ((P24 & 1) != 0 && SW == SWEEP_REV && (FL & 1)) o2 = p24_unpack_raw(o2);
     if constexpr ((P24 & 2) != 0 && SW == SWEEP_ADJ_FWD) o2 = p24_unpack_raw(o2);
     if constexpr ((P24 & 2) != 0 && SW == SWEEP_ADJ_REV && (FL & 1)) o2 = p24_unpack_raw(o2);
@@ -260,7 +296,7 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             s[t] = sv.x; s[t + 1] = sv.y; c[t] = cv.x; c[t + 1] = cv.y;
         }
         if constexpr (FL & 1) DUDF_STR(RL, (P24 & 1) != 0, a.S, ub, lo, s);
-        if constexpr (FL & 2) DUDF_ST(a.C, ub, vo, c);
+        if constexpr (FL & 2) { if constexpr ((P24 & 4) != 0) DUDF_STC24(a.C, ub, lo.ct, c); else DUDF_ST(a.C, ub, vo, c); }
         out = s;
     } else if constexpr (SW == SWEEP_REV) {          // acc = a_l, o1 = c_l, o2 = s_l
         out = a.w0 * o1 * acc;                       // q_l = w0 c_l a_l
@@ -287,7 +323,8 @@ __device__ __forceinline__ f32x4 epilogue(const SweepArgs& a, f32x4 acc, f32x4 o
             zs[t] = isv ? sv : acc[t];
             out[t] = isv ? sv : a.w0 * cv * acc[t];
         }
-        DUDF_ST(a.C, ub, lo.c, c);   // one copy per quad (LaneOff): the four lanes hold the same bits and write the same granule — no branch
+        // one copy per quad (LaneOff): the four lanes hold the same bits and write the same granule — no branch
+        if constexpr ((P24 & 4) != 0) DUDF_STC24(a.C, ub, lo.ct, c); else DUDF_ST(a.C, ub, lo.c, c);
         DUDF_ST(a.ZS, ub, vo, zs);
         if constexpr (FL & 1) DUDF_STR(RL, (P24 & 1) != 0, a.S, ub, lo, out);
     } else if constexpr (SW == SWEEP_REV_H) {        // o1 = c, o2 = s|zdot^k
@@ -355,23 +392,23 @@ __device__ __forceinline__ void epilogue_loads(const SweepArgs& a, int64_t ub, c
     o1 = f32x4{0, 0, 0, 0}; o2 = o1; o3 = o1;
     const unsigned vo = lo.v;
     if constexpr (SW == SWEEP_REV) {
-        o1 = DUDF_LD(a.C, ub, vo);
+        o1 = DUDF_LDC((P24 & 4) != 0, a.C, ub, lo);
         if constexpr (FL & 1) o2 = DUDF_LDB((P24 & 1) != 0, a.S, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_FWD) {
-        o1 = DUDF_LD(a.C, ub, vo);
+        o1 = DUDF_LDC((P24 & 4) != 0, a.C, ub, lo);
         o2 = DUDF_LDB((P24 & 2) != 0, a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV) {
-        o1 = DUDF_LD(a.C, ub, vo);
+        o1 = DUDF_LDC((P24 & 4) != 0, a.C, ub, lo);
         if constexpr (FL & 1) o2 = DUDF_LDB((P24 & 2) != 0, a.E, ub, lo);      // no df/dx terms (loss_s2): e_l == 0
     } else if constexpr (SW == SWEEP_REV_H) {
-        o1 = DUDF_LD(a.C, ub, lo.c);
+        o1 = DUDF_LDC((P24 & 4) != 0, a.C, ub, lo);
         o2 = DUDF_LD(a.ZS, ub, vo);
     } else if constexpr (SW == SWEEP_ADJ_FWD_H) {
-        o1 = DUDF_LD(a.C, ub, lo.c);
+        o1 = DUDF_LDC((P24 & 4) != 0, a.C, ub, lo);
         o2 = DUDF_LD(a.ZS, ub, vo);
         o3 = DUDF_LDB((P24 & 2) != 0, a.R, ub, lo);
     } else if constexpr (SW == SWEEP_ADJ_REV_H) {
-        o1 = DUDF_LD(a.C, ub, lo.c);
+        o1 = DUDF_LDC((P24 & 4) != 0, a.C, ub, lo);
         o2 = DUDF_LD(a.ZS, ub, vo);
         o3 = DUDF_LDB((P24 & 2) != 0, a.E, ub, lo);
     }

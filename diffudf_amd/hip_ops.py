@@ -49,7 +49,8 @@ def sweeps_on_bf16(hidden, layers, w0=30.0):
 
 
 def stash_mode(cfg):
-    """0: the training stash is all fp32; 1: its backward-only arrays hold 24-bit values (dudf_stash_mode, include/dudf_hip.h)."""
+    """Bit mask of the training stash arrays held at 24 bits (dudf_stash_mode, include/dudf_hip.h): 0 = all fp32, 6 = R, E, C (the
+    default of 256-wide networks), 7 = S, Q, A, Z as well (DUDF_STASH=17p24)."""
     return int(_lib.load().dudf_stash_mode(ctypes.byref(cfg)))
 
 

@@ -223,13 +223,16 @@ int dudf_debug_stash_layout(const dudf_net_cfg* cfg, int64_t n, int64_t n_hess, 
 
 /* Format of the stash a training workspace of this network keeps between the sweeps and the weight-gradient GEMM
  * (the activations `backward()` needs — what autograd saves for reference src/model.py:116-135 / src/diff_operators.py:208-212),
- * as a bit mask of the arrays held as fp32 values rounded to 24 bits (relative error <= 2^-17), 12 bytes per 4 values,
- * tile-major [layer][feature/16][column/16][64 lanes][3 dwords]:
- *   bit 1 (2) = R, E — read only by the adjoint sweeps; bit 0 (1) = S, Q, A, Z — the weight-gradient GEMM's operands.
+ * as a bit mask of the arrays held at 24 bits, 12 bytes per 4 values, tile-major [layer][feature/16][column/16][64 lanes][3 dwords]:
+ *   bit 1 (2) = R, E — read only by the adjoint sweeps — and bit 0 (1) = S, Q, A, Z — the weight-gradient GEMM's operands — as
+ *               fp32 values rounded to their top three bytes (relative error <= 2^-17);
+ *   bit 2 (4) = C = cos(w0 z_l) as FIXED POINT on a 2^-22 grid (absolute error <= 2^-23: the size of the sin/cos polynomials' own).
  *   0 = every array fp32, [layer][feature/4][column][4]  (DUDF_STASH=17; every network that is not 256 wide);
- *   2 = the default of 256-wide networks: every parity tolerance and the 12-step beetle trajectory hold unchanged;
- *   3 = DUDF_STASH=17p24, opt-in: single-step tolerances hold, the beetle trajectory drifts to 4e-4 (tests/test_stash_p24_gpu.py).
- * C and ZS are always fp32.  -1 = bad cfg.  dudf_debug_read_stash decodes every format. */
+ *   6 = the default of 256-wide networks (15 instead of 17 array-layer units per step): every parity tolerance and the 12-step
+ *       beetle trajectory hold unchanged;
+ *   7 = DUDF_STASH=17p24, opt-in (12.75 units): single-step tolerances hold, the beetle trajectory drifts to 4e-4
+ *       (tests/test_stash_p24_gpu.py).
+ * ZS is always fp32.  -1 = bad cfg.  dudf_debug_read_stash decodes every format. */
 int dudf_stash_mode(const dudf_net_cfg* cfg);
 
 /* One training batch on the GPU — replaces `sampleTrainingData` (reference src/dataset.py:14-70, open3d on the CPU)

@@ -36,14 +36,15 @@ def test_host_only_calls():
     assert lib.dudf_theta_count(ctypes.byref(cfg)) == 461825
     nb = lib.dudf_workspace_bytes(ctypes.byref(cfg), 29970)
     np_ = (29970 + 63) // 64 * 64
-    # seven stash arrays per layer and column: all fp32 (mode 0), R and E at 3 bytes per value (mode 2, the default), or all six
-    # backward-only arrays at 3 bytes + C at 4 (mode 3)
-    per_value = {0: 7 * 4, 2: 5 * 4 + 2 * 3, 3: 6 * 3 + 4}[lib.dudf_stash_mode(ctypes.byref(cfg))]
+    # seven stash arrays per layer and column: all fp32 (mask 0), R, E and C at 3 bytes per value (mask 6, the default), or all
+    # seven at 3 bytes (mask 7)
+    per_value = {0: 7 * 4, 6: 4 * 4 + 3 * 3, 7: 7 * 3}[lib.dudf_stash_mode(ctypes.byref(cfg))]
     assert nb >= per_value * 8 * 256 * np_
     nbh = lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 29970, 9990)       # on-surface third on the Hessian path
     cols = (4 * 9990 + 63) // 64 * 64 + (19980 + 63) // 64 * 64
     assert nbh >= (per_value + 4) * 8 * 256 * cols                            # + ZS (fp32)
-    assert lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 512, 30.0))) == 0   # 512-wide layers relay their operands through the stash: fp32
+    assert lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 512, 30.0))) in (0, 6)   # 512-wide layers relay S, Q, A, Z through the stash: those stay fp32
+    assert lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 128, 30.0))) == 0
     assert lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 100, 30.0))) == -1
     assert lib.dudf_workspace_bytes_hess(ctypes.byref(cfg), 10, 11) == 0
     bad = _lib.NetCfg(3, 8, 100, 30.0)

@@ -1,16 +1,17 @@
 # coding: utf-8
-"""GPU: the stash formats (dudf_stash_mode).
+"""GPU: the stash formats (dudf_stash_mode, a bit mask).
 
-  mode 2, the DEFAULT of 256-wide networks: R and E — the two arrays only the adjoint sweeps read — hold fp32 values rounded to 24
-          bits (2^-17 relative), tile-major: 16 instead of 17 array-layer units, every tolerance unchanged (the whole GPU suite
-          runs in this mode), the 12-step beetle trajectory at 3e-7;
-  mode 3, opt-in (DUDF_STASH=17p24): S, Q, A, Z as well, the weight-gradient GEMM reading them through transposed LDS fragment
-          reads: 13.75 units, step -9 %.  Built, measured, and NOT the default.  What this file pins for it:
+  mask 6, the DEFAULT of 256-wide networks: R and E — the two arrays only the adjoint sweeps read — hold fp32 values rounded to 24
+          bits (2^-17 relative), and C = cos(w0 z_l) is 24-bit fixed point on a 2^-22 grid (absolute error 2^-23, the size of the
+          sin/cos polynomials' own error); all three tile-major: 15 instead of 17 array-layer units, every tolerance unchanged (the
+          whole GPU suite runs in this mode), the 12-step beetle trajectory at 3e-7 .. 5e-7 like fp32;
+  mask 7, opt-in (DUDF_STASH=17p24): S, Q, A, Z as 24-bit floats as well, the weight-gradient GEMM reading them through transposed
+          LDS fragment reads: 12.75 units.  Built, measured, and NOT the default.  What this file pins for it:
   * every single-step tolerance of tests/test_hip_parity.py and tests/test_full_size_oracle_gpu.py holds unchanged in that
     mode (terms 1e-5, d(theta) 1e-4 / 5e-4 with the Hessian term, stash columns 5e-5 / 2e-4) — the kernels are right;
   * the 12-step beetle trajectory does NOT hold the north star's 1e-4: Adam divides every gradient component by its own
     magnitude, so the components that sit at the noise floor flip sign, and a floor 128 times higher (2^-17 against fp32's
-    2^-24) moves the loss curve by 1e-4 .. 4e-4 within 12 steps (measured; fp32 stash and mode 2: 3e-7).  That is why mode 3
+    2^-24) moves the loss curve by 1e-4 .. 4e-4 within 12 steps (measured; fp32 stash and mask 6: 3e-7).  That is why mask 7
     stays opt-in — the test asserts the drift stays of that order so that the record in DESIGN.md §6 remains true.
 Each case runs in a child process: the stash format is chosen when the library first answers dudf_stash_mode."""
 import os
@@ -34,13 +35,13 @@ def test_stash_modes_are_selected():
     code = ("import ctypes; from diffudf_amd import _lib; lib = _lib.load(); "
             "print(lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 256, 30.0))), lib.dudf_stash_mode(ctypes.byref(_lib.NetCfg(3, 8, 512, 30.0))))")
     env = dict(os.environ); env.pop("DUDF_STASH", None)
-    assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["2", "0"]   # default: R, E; 512-wide: fp32
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["6", "6"]   # default: R, E, C — at 256 and 512
     env["DUDF_STASH"] = "17"
     assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["0", "0"]
-    env["DUDF_STASH"] = "17p24"
-    assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["3", "0"]
+    env["DUDF_STASH"] = "17p24"                          # (512-wide layers relay S, Q, A, Z through the stash: those stay fp32)
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["7", "6"]
     env["DUDF_WGRAD"] = "f32"                            # a weight-gradient kernel that reads fp32 rows: its operands stay fp32
-    assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["2", "0"]
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["6", "6"]
     env["DUDF_SWEEP"] = "f32"                            # ... and sweeps that cannot write the 24-bit arrays: fp32 stash
     assert subprocess.check_output([sys.executable, "-c", code], cwd=REPO, env=env, text=True).split() == ["0", "0"]
 
