@@ -1431,8 +1431,12 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         float cmax = 0.f;                              // fp16x3: largest |output| of this lane's rows of the column
 #pragma unroll
         for (int T = 0; T < PD; ++T) ld(T, T);
+        // (two halves of 16 tiles, each its own fully unrolled loop: as ONE loop of 32 the larger tails — the quads' adjoint forward
+        //  sweep with 24-bit arrays — exceed hipcc's size limit for a forced unroll, and the rolled loop indexes acc[] dynamically)
+        auto burst_half = [&](auto t0c) {
+        constexpr int T0 = decltype(t0c)::value;
 #pragma unroll
-        for (int T = 0; T < G::NT; ++T) {
+        for (int T = T0; T < T0 + G::NT / 2; ++T) {
             const int s = T % PD;
             f32x4 z = acc[T];
             const f32x4 zero4 = {0, 0, 0, 0};
@@ -1457,6 +1461,9 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             }
             acc[T] = f32x4{0, 0, 0, 0};
         }
+        };
+        burst_half(std::integral_constant<int, 0>{});
+        burst_half(std::integral_constant<int, G::NT / 2>{});
         if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) lds_max_wave(lds_amax + layer, tmax.t); }
         if constexpr (kColScale) {                     // the next layer's B operand = these outputs: scale the column below 2^15
             cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
