@@ -1433,10 +1433,11 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
         for (int T = 0; T < PD; ++T) ld(T, T);
         // (two halves of 16 tiles, each its own fully unrolled loop: as ONE loop of 32 the larger tails — the quads' adjoint forward
         //  sweep with 24-bit arrays — exceed hipcc's size limit for a forced unroll, and the rolled loop indexes acc[] dynamically)
-        auto burst_half = [&](auto t0c) {
-        constexpr int T0 = decltype(t0c)::value;
+        //  The jets' tail is too large even so; their loop stays the single rolled one it has been since round 3.)
+        auto burst_range = [&](auto t0c, auto t1c) {
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
 #pragma unroll
-        for (int T = T0; T < T0 + G::NT / 2; ++T) {
+        for (int T = T0; T < T1; ++T) {
             const int s = T % PD;
             f32x4 z = acc[T];
             const f32x4 zero4 = {0, 0, 0, 0};
@@ -1462,8 +1463,12 @@ __device__ __forceinline__ void sweep_tile_w(const SweepArgs& a, const int g_fir
             acc[T] = f32x4{0, 0, 0, 0};
         }
         };
-        burst_half(std::integral_constant<int, 0>{});
-        burst_half(std::integral_constant<int, G::NT / 2>{});
+        if constexpr (is_jet(SW)) {
+            burst_range(std::integral_constant<int, 0>{}, std::integral_constant<int, G::NT>{});
+        } else {
+            burst_range(std::integral_constant<int, 0>{}, std::integral_constant<int, G::NT / 2>{});
+            burst_range(std::integral_constant<int, G::NT / 2>{}, std::integral_constant<int, G::NT>{});
+        }
         if constexpr (kRow >= 0) { if (layer < kMaxAmaxLayers) lds_max_wave(lds_amax + layer, tmax.t); }
         if constexpr (kColScale) {                     // the next layer's B operand = these outputs: scale the column below 2^15
             cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
