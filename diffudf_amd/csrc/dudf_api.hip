@@ -72,7 +72,8 @@ bool use_bf16_sweeps() {
 //   "17"    = mask 0: every array fp32, 17 array-layer units per column (rounds 1-3);
 //   default = mask 6: R and E as 24-bit floats, C as 24-bit fixed point, tile-major (dudf_internal.h): 15 units.  Every tolerance
 //             holds, the 12-step beetle trajectory included (3e-7 .. 5e-7, as with fp32);
-//   "17p24" = mask 7: S, Q, A, Z as 24-bit floats as well (12.75 units): opt-in — every single-step tolerance holds, but 2^-17
+//   "15"    = the default, spelled out;
+//   "17p24" (or "15p24") = mask 7: S, Q, A, Z as 24-bit floats as well (12.75 units): opt-in — every single-step tolerance holds, but 2^-17
 //             noise on the weight-gradient GEMM's operands moves the beetle trajectory by 4e-4 (bar 1e-4; tests/test_stash_p24_gpu.py).
 // The 24-bit arrays exist in the fp16x3 training kernels of 256- and 512-wide networks (R, E, C) and in the cooperative-split
 // weight-gradient GEMM of 256-wide ones (S, Q, A, Z); an A/B switch that routes a kernel elsewhere drops the corresponding bits.
