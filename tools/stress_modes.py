@@ -1,0 +1,76 @@
+# coding: utf-8
+"""Edge shapes through the training path in the stash format of this process (DUDF_STASH), written to an .npz; run it once per
+format and compare:  DUDF_STASH=17 python tools/stress_modes.py /tmp/a.npz;  python tools/stress_modes.py /tmp/b.npz;
+python tools/stress_modes.py --compare /tmp/a.npz /tmp/b.npz
+Shapes: one / two hidden matrices, the deepest networks the 24-bit kernels take, column counts of 1, 17, a multiple of 2048
+(skewed row stride), all points on the Hessian path, none, a third; widths 256 and 512."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+CASES = [  # hidden, n, n_hess, seed
+    ([256, 256], 1, 0, 1), ([256, 256], 17, 17, 2), ([256] * 3, 2048, 0, 3), ([256] * 3, 4096, 1365, 4),
+    ([256] * 8, 1000, 333, 5), ([256] * 32, 300, 100, 6), ([256] * 33, 200, 0, 7),
+    ([512, 512], 1, 0, 8), ([512, 512], 129, 129, 9), ([512] * 3, 2048, 0, 10), ([512] * 3, 4096, 1365, 11),
+    ([512] * 8, 700, 233, 12), ([512] * 34, 150, 50, 13),
+]
+
+
+def run(out):
+    import torch
+    from diffudf_amd import hip_ops as hip, synth
+    res = {}
+    for ci, (hidden, n, nh, seed) in enumerate(CASES):
+        P = synth.siren_params(hidden, seed=seed, dtype=np.float64)
+        theta = synth.flatten_params([(w.astype(np.float32), b.astype(np.float32)) for w, b in P])
+        x, nrm, sdf = synth.training_batch(max(n, 3), seed=seed + 1)
+        x, nrm, sdf = x[:n], nrm[:n], sdf.reshape(-1)[:n].copy()
+        # the Hessian-path points lead and are the on-surface ones
+        sdf[:nh] = 0.0
+        sdf[nh:] = np.where(sdf[nh:] == 0, 0.01, sdf[nh:])
+        cfg = hip.make_cfg(hidden)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        th, xd, nd, sd = dev(theta), dev(x), dev(nrm), dev(sdf)
+        W = [1e4, 1e4, 1e4 if nh else 0.0, 1e3]
+        ws = hip.workspace_for(cfg, n, "cuda", n_hess=nh) if nh else hip.workspace_for(cfg, n, "cuda")
+        kw = {"n_hess": nh} if nh else {}
+        t = hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W, 100.0, ws, **kw)
+        d = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W, 100.0, torch.ones(4, device="cuda"), None, ws, **kw)
+        torch.cuda.synchronize()
+        res[f"t{ci}"] = t.cpu().numpy(); res[f"d{ci}"] = d.cpu().numpy()[::97]; res[f"n{ci}"] = np.array([float(d.double().norm())])
+        print(f"case {ci}: {hidden[0]}x{len(hidden)} n={n} n_hess={nh}  mode {hip.stash_mode(cfg)}  terms {t.cpu().numpy()}  |dtheta| {float(d.abs().max()):.4e}",
+              flush=True)
+        # loss_s2 (no df/dx terms) on the same workspace shape
+        if nh == 0 and n >= 3:                                # (the unbiased std of one point is NaN, in the reference too)
+            sdf2 = sdf.copy(); sdf2[:n // 3 + 1] = 0.0          # loss_s2 looks at the on-surface points only
+            sd2 = dev(sdf2)
+            st = hip.s2_forward_stats(cfg, th, xd, sd2, ws)
+            d2 = hip.loss_backward(cfg, hip.LOSS_S2, th, xd, nd, sd2, n, [1e5, 1e5], 100.0, torch.ones(4, device="cuda"), st, ws)
+            assert float(d2.abs().max()) > 0
+            torch.cuda.synchronize()
+            res[f"s{ci}"] = d2.cpu().numpy()[::97]
+    np.savez(out, **res)
+
+
+def compare(a, b):
+    A, B = np.load(a), np.load(b)
+    worst = 0.0
+    for k in A.files:
+        x, y = A[k].astype(np.float64), B[k].astype(np.float64)
+        e = np.abs(x - y).max() / max(np.abs(x).max(), 1e-300)
+        ok = np.isfinite(y).all() and e < (1e-5 if k[0] == "t" else 3e-4)
+        worst = max(worst, e)
+        print(f"{k}: rel diff {e:.2e} {'ok' if ok else 'FAIL'}")
+        assert ok, k
+    print("worst", worst)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--compare":
+        compare(sys.argv[2], sys.argv[3])
+    else:
+        run(sys.argv[1])
