@@ -306,7 +306,7 @@ def test_fp16x3_range_scaling(hip, scale):
     g1 = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.ones(4, device="cuda"), None, ws).clone()
     gs = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, W_S1EIK, 100.0, torch.full((4,), scale, device="cuda"), None, ws)
     assert torch.isfinite(gs).all()
-    # 2e-6: fp32's own noise at 700 points — held by the default stash (R and E at 24 bits: measured 3.5e-7).  With the opt-in
+    # 2e-6: fp32's own noise at 700 points — held by the default stash (R, E, C at 24 bits: measured 3.5e-7 with R, E alone).  With the opt-in
     # all-24-bit stash (dudf_stash_mode 7) a cotangent scaled by a NON-power of two rounds the weight-gradient GEMM's operands at
     # other places — 2^-17 = 7.6e-6 per element, the format's bound, is then the bar for this self-consistency check (measured
     # 2.0e-6); powers of two commute with the rounding and keep the fp32 bar.
@@ -344,7 +344,7 @@ def test_fp16x3_range_scaling_hessian_quads(hip, scale):
     assert torch.isfinite(gs).all()
     # (opt-in all-24-bit stash: a cotangent scaled by a non-power of two rounds the stashed operands at other places — the format's
     #  own 2^-17 per element bounds this self-consistency check there, see test_fp16x3_range_scaling; measured 8.0e-6.  Default
-    #  stash, R and E at 24 bits: 1.6e-6)
+    #  stash, R, E (and C) at 24 bits: 1.6e-6)
     lin = rel((gs.double() / scale).cpu().numpy(), g1.double().cpu().numpy())
     print(f"linearity in the cotangent (quads), scale {scale:g}, stash mode {hip.stash_mode(cfg)}: {lin:.2e}")
     assert lin < (5e-6 if hip.stash_mode(cfg) != 7 else 2e-5), scale

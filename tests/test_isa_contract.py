@@ -107,7 +107,7 @@ def test_f16_sweep_wait_counts(tmp_path, bf16_asm):
             # strict (the other sweeps' operand waits, placed by the compiler, retire the older DMA pieces anyway)
             if key[0] == 0 and force == 0:
                 assert sum(1 for n, late, slack in v["waits"] if slack == 0) >= 7, (force, key, v["waits"])
-    # the builds that keep stash arrays at 24 bits (training variants of the plain columns and of the quads) — f16r: R and E (the
+    # the builds that keep stash arrays at 24 bits (training variants of the plain columns and of the quads) — f16r: R, E and C (the
     # default stash of 256-wide networks), f16p: S, Q, A, Z as well (opt-in): same step structure, dwordx3 stash accesses — the
     # same replay must hold
     p24_keys = {(0, 3), (1, 1), (2, 0), (3, 1), (3, 0), (4, 1), (5, 1), (6, 0), (7, 0)}

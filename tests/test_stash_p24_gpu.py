@@ -1,7 +1,7 @@
 # coding: utf-8
 """GPU: the stash formats (dudf_stash_mode, a bit mask).
 
-  mask 6, the DEFAULT of 256-wide networks: R and E — the two arrays only the adjoint sweeps read — hold fp32 values rounded to 24
+  mask 6, the DEFAULT of 256- and 512-wide networks: R and E — the two arrays only the adjoint sweeps read — hold fp32 values rounded to 24
           bits (2^-17 relative), and C = cos(w0 z_l) is 24-bit fixed point on a 2^-22 grid (absolute error 2^-23, the size of the
           sin/cos polynomials' own error); all three tile-major: 15 instead of 17 array-layer units, every tolerance unchanged (the
           whole GPU suite runs in this mode), the 12-step beetle trajectory at 3e-7 .. 5e-7 like fp32;
