@@ -429,7 +429,10 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
 // phase stamps of the LAST steady-state stage of one workgroup (timing experiments): [wave][stamp], shader-clock cycles
 __device__ unsigned long long g_wstamp[8][12];
 extern "C" int dudf_dbg_wstamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), sizeof(g_wstamp)); }
-#define DUDF_WSTAMP(i) do { if constexpr (HOT) { __builtin_amdgcn_sched_barrier(0); wst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define DUDF_WSTAMP(i) do { if constexpr (HOT) { __builtin_amdgcn_sched_barrier(0); if (it == DUDF_WSTAMP_IT) wst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#ifndef DUDF_WSTAMP_IT
+#define DUDF_WSTAMP_IT 60
+#endif
 #else
 #define DUDF_WSTAMP(i) do { } while (0)
 #endif
@@ -911,10 +914,14 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
             __builtin_amdgcn_sched_barrier(0);
             publish(flag0 + 32u + 4u * (unsigned)wave, (unsigned)it + 1u);                       // fragment reads of stage `it` done
             constexpr int BW = (BI + 2) % 3;
+            DUDF_WSTAMP(2);
             if (HOT || it + 2 < nit) poll(0u, (unsigned)it, 0u, 0u);                             // image it - 1 read by everybody: its buffer is free
+            DUDF_WSTAMP(4);
             if constexpr (HOT) {
                 if constexpr (!(DBG & 1)) wait_raw(r, std::integral_constant<int, 8>{});         // (DBG: timing experiments, wrong results)
+                DUDF_WSTAMP(6);
                 if constexpr (!(DBG & 8)) split_store(it + 2, r, BW);
+                DUDF_WSTAMP(8);
                 if constexpr (!(DBG & 1)) load_raw(it + 5, r);
                 publish(flag0 + 4u * (unsigned)wave, (unsigned)it + 3u);                         // images 0 .. it + 2 written
             } else if (it + 2 < nit) {

@@ -49,8 +49,8 @@ if hasattr(lib, "dudf_dbg_wstamps") or True:
         wb = np.zeros((8, 12), dtype=np.uint64)
         assert fnw(wb.ctypes.data_as(ctypes.c_void_p)) == 0
         t0 = int(wb[:, 0].min())
-        print("== wgrad_hidden, one stage (cycles): start | A frags issued | slice0 mfma0 | slice1 mfma1 | slice2 mfma2 | slice3 mfma3 | loads issued | barrier passed")
+        print("== wgrad_hidden, one stage (cycles): 0 start | 1 A frags issued (past the first poll) | 3 5 7 9 MFMA groups issued | 2 reads published | 4 buffer free | 6 loads landed | 8 split written | 10 loads issued, image published")
         for w in range(8):
-            print("  wave %d: " % w + " ".join("%6d" % (int(v) - t0) for v in wb[w]))
+            print("  wave %d: " % w + " ".join("%d:%6d" % (i, int(wb[w][i]) - t0) for i in (0, 1, 3, 5, 7, 9, 2, 4, 6, 8, 10)))
     except AttributeError:
         pass
