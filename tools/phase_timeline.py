@@ -54,3 +54,14 @@ if hasattr(lib, "dudf_dbg_wstamps") or True:
             print("  wave %d: " % w + " ".join("%d:%6d" % (i, int(wb[w][i]) - t0) for i in (0, 1, 3, 5, 7, 9, 2, 4, 6, 8, 10)))
     except AttributeError:
         pass
+
+# sixteen-wave experiment (DUDF_WGRAD_W16=1, -DDUDF_WGRAD_DBG=32): stage 40 of one workgroup, six stamps per wave
+if os.environ.get("DUDF_WGRAD_W16") == "1":
+    fnw = lib.dudf_dbg_wstamps
+    fnw.argtypes = [ctypes.c_void_p]
+    wb = np.zeros(96, dtype=np.uint64)
+    assert fnw(wb.ctypes.data_as(ctypes.c_void_p)) == 0
+    wb = wb.reshape(16, 6); t0 = int(wb[:, 0].min())
+    print("== W16 stage: start | fetch (+ MFMAs if first) | raw landed | split + DMA issued | MFMAs (if second) | barrier passed")
+    for w in range(16):
+        print("  wave %2d (simd %d, %s): " % (w, w % 4, "M first" if (w >> 2) & 1 else "S first") + " ".join("%6d" % (int(v) - t0) for v in wb[w]))
