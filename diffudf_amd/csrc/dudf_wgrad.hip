@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
 #endif
 #ifndef DUDF_WGRAD_DBG
 #define DUDF_WGRAD_DBG 0           // timing experiments only (wrong results): 1 no loads, 2 no barrier, 4 no MFMA, 8 no split,
-#endif                             // 16 no LDS fragment reads
+#endif                             // 16 no LDS fragment reads, 32 stage stamps, 64 no output atomics
 #if DUDF_WGRAD_DBG & 32
 // phase stamps of the LAST steady-state stage of one workgroup (timing experiments): [wave][stamp], shader-clock cycles
 __device__ unsigned long long g_wstamp[8][12];
@@ -980,7 +980,11 @@ __device__ __forceinline__ void wgrad_hidden_bf16p_body(const WgradArgs& a) {
 #pragma unroll
                 for (int n = 0; n < W::NTL; ++n) {
                     const int i = (wi * W::NTL + n) * 32 + l32;
+#if DUDF_WGRAD_DBG & 64
+                    asm volatile("" :: "v"(acc[m][n][e]));               // timing experiment: no output atomics
+#else
                     atomicAdd(dW + (int64_t)o * a.Hs + i, SP != 0 ? acc[m][n][e] * inv_p : acc[m][n][e]);
+#endif
                 }
             }
         if (p_oper == 0 && i_off == 0) {                          // bias gradient: sum the four column groups of a quad first
