@@ -121,3 +121,32 @@ def test_latent_vector_through_evaluate(G, tag):
         evaluate(m, xs, latent_vec=lat, hessians=np.zeros((xs.shape[0], 3, 3)))
     with pytest.raises(DudfError):                       # training a latent-conditioned network is not a reference recipe
         m(torch.from_numpy(np.concatenate([np.repeat(lat.numpy(), xs.shape[0], 0), xs], 1)).cuda())
+
+
+def test_ww_at_width_512_against_the_oracle():
+    """`ww != w0` through the 512-wide kernel (its own tail burst and relay; R, E, C at 24 bits): value, df/dx, the `loss_s1` terms
+    and d(theta) with and without the Hessian term against the oracle run with the frequency pair (pinned by the fixture cases
+    above to the reference's own outputs)."""
+    from diffudf_amd import hip_ops as hip
+    hid, n, seed = [512] * 3, 700, 21
+    P = synth.siren_params(hid, seed=seed, w0=15.0, dtype=np.float64)
+    P32 = [(w.astype(np.float32), b.astype(np.float32)) for w, b in P]
+    x, nrm, sdf = synth.training_batch(n, seed=seed + 1)
+    cfg = hip.make_cfg(hid, 30.0, ww=15.0)
+    th = torch.from_numpy(synth.flatten_params(P32)).cuda()
+    xd, nd, sd = [torch.from_numpy(a).cuda() for a in (x, nrm, sdf.reshape(-1))]
+    f, g = hip.query(cfg, th, xd)
+    yo, go, _ = O.query(P, x.astype(np.float64), want_grad=True, want_hess=False, w0=(30.0, 15.0))
+    assert rel(f.cpu().numpy(), yo) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5
+    n_on = int((sdf.reshape(-1) == 0).sum())
+    for name, w, tol in (("s1eik", [1e4, 1e4, 0.0, 1e3], 1e-4), ("s1full", [1e4, 1e4, 1e4, 1e3], 5e-4)):
+        nh = n_on if w[2] else 0
+        ws = hip.workspace_for(cfg, n, "cuda", n_hess=nh) if nh else hip.workspace_for(cfg, n, "cuda")
+        kw = {"n_hess": nh} if nh else {}
+        terms = hip.loss_forward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, w, 100.0, ws, **kw).cpu().numpy()
+        dth = hip.loss_backward(cfg, hip.LOSS_S1, th, xd, nd, sd, n, w, 100.0, torch.ones(4, device="cuda"), None, ws, **kw).cpu().numpy()
+        t_ref, gr, _ = O.loss_and_grad("s1", P, x.astype(np.float64), nrm.astype(np.float64), sdf.astype(np.float64), w, 100.0, w0=(30.0, 15.0))
+        flat = np.concatenate([np.concatenate([a.reshape(-1), b.reshape(-1)]) for a, b in gr])
+        et, ed = rel(terms, np.array([float(v) for v in t_ref.values()])), rel(dth, flat)
+        print(f"ww 512x3 {name}: stash mode {hip.stash_mode(cfg)} terms {et:.1e} dtheta {ed:.1e}")
+        assert et < 1e-5 and ed < tol
