@@ -401,6 +401,11 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
+    if "--share-device" in sys.argv:
+        # n processes on ONE GPU: one hardware queue each.  With the default four per process 8 ranks oversubscribe the chip's 24 user
+        # queue slots, the hardware scheduler starts time-slicing them, and on this platform a restored queue then skips or replays ONE
+        # dispatch on single XCDs (8/120 runs against 0/120 on the same box)
+        env.setdefault("GPU_MAX_HW_QUEUES", "1")
     if os.environ.get("DUDF_BENCH_DRY_LAUNCH") == "1":  # tests: show what would be started, start nothing
         print(json.dumps({"launch": cmd, "cuda_initialized": torch.cuda.is_initialized()}))
         return 0
@@ -422,11 +427,16 @@ def main():
                     help="run-time option of the library (dudf_set_option; include/dudf_hip.h lists them), e.g. --opt stash=7 "
                          "--opt split=0; A/B runs only: the headline is the default build")
     ap.add_argument("--collectives", choices=["staggered", "fused"], default=None, help="N > 1: TrainEngine's all-reduce schedule")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank on cuda:0 over gloo (RCCL refuses two ranks on one device).  A functional "
+                         "check of the sharded path, never a measurement: the JSON line says \"share_device\": true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary 8x512 blocks (125 000 points per GPU; 1 M points on one GPU)")
     ap.add_argument("--no-config3-1m", action="store_true", help="skip only the 8x512 / 1 000 000-points-on-one-GPU block (110 GB workspace)")
     args = ap.parse_args()
 
+    if args.share_device:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")  # read by the HIP runtime when this process first touches the GPU (see self_launch)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -436,9 +446,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # DUDF_TEST_SHARE_GPU=1: functional check of the N>1 path on a ONE-GPU box (all ranks on cuda:0, gloo instead of
-    # RCCL, which refuses two ranks on one device).  Never set for a measurement.
-    share = os.environ.get("DUDF_TEST_SHARE_GPU") == "1"
+    share = args.share_device
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -492,6 +500,7 @@ def main():
             "metric": "train points/sec (SIREN fwd+∇x+Eikonal loss+bwd), 256×8 net, 100k pts" if headline
             else f"train points/sec (SIREN fwd+∇x+{'Eikonal loss' if args.loss == 'eikonal' else 'Hessian+full loss_s1'}+bwd), "
                  f"{args.hidden}×{args.layers} net, {args.points} pts [secondary configuration]",
+            **({"share_device": True, "share_device_note": "all ranks on cuda:0 over gloo: a functional check, not a measurement"} if args.share_device else {}),
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "ms_per_step_median": info["median_ms"], "ms_per_step_min": info["min_ms"],
             "ms_per_step_max": info["max_ms"],

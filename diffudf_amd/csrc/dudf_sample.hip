@@ -338,7 +338,11 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SampleArgs a) {
     if (live && part == 0) {
         a.x[i * 3] = px; a.x[i * 3 + 1] = py; a.x[i * 3 + 2] = pz;
         a.normals[i * 3] = nx; a.normals[i * 3 + 1] = ny; a.normals[i * 3 + 2] = nz;
-        a.sdf[i] = query ? (float)sqrt(best) : known;
+        // off-surface samples keep sdf > 0: a far point that lies exactly on a triangle, or a near point whose offset rounds to 0, would
+        // otherwise carry the "on surface" marker (sdf == 0) in the wrong stratum — the loss kernels' n_hess layout check turns that
+        // into NaN for the rest of the run.  FLT_MIN as a distance is 0 to every later computation.
+        const float sd = query ? (float)sqrt(best) : known;
+        a.sdf[i] = (i < n_on_l) ? sd : fmaxf(sd, 1.17549435e-38f);
     }
 }
 

@@ -316,6 +316,11 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
             const float sk = quad_sum(isv ? 0.f : zb * amax_true);
             bound = extra + a.w0 * (amax_true + (isv ? a.w0 * sk : 0.f));
         }
+        // 2^-10 of head room: the bound is formed in rounded fp32 and from the UNROUNDED e_l / zdot_l maxima, while the tails round
+        // on their own path (and R, E come back rounded to 16 significant bits): a column whose bound sits an ulp under a power of two
+        // could hand the fixed-point stash a value a grid step outside [-1, 1] 2^E, which fx24_pack would wrap to +5 2^E.
+        // Once per layer and column, not per value; costs a bit of the column's precision in 0.14 % of the scale decisions.
+        bound *= 1.0009765625f;
         unsigned E = (__float_as_uint(bound) >> 23) & 255u;    // bound < 2^(E - 126)
         E = E < 27u ? 27u : (E > 250u ? 250u : E);             // all-zero (padding) columns, infinities: any finite scale will do
         sb = __uint_as_float((268u - E) << 23);                // 2^(15 - (E - 126))
@@ -870,7 +875,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
             float mm = 0.f;
 #pragma unroll
             for (int w = 0; w < NWB; ++w) mm = fmaxf(mm, cmx[w * 16 + li]);
-            const float bound = a.w0 * (mm * unscale) + eb;
+            const float bound = (a.w0 * (mm * unscale) + eb) * 1.0009765625f;      // (2^-10 of head room: see set_scale)
             unsigned E = (__float_as_uint(bound) >> 23) & 255u;
             E = E < 27u ? 27u : (E > 250u ? 250u : E);
             sb = __uint_as_float((268u - E) << 23);

@@ -25,7 +25,7 @@ def generate_mc(model, gt_mode, device, N, output_path, alpha=None, algorithm='m
     """`luts`: the Lewiner tables for the MeshUDF half (dict, path or None = look them up; see the module docstring)."""
     if from_file is not None:
         model = SIREN(n_in_features=3, n_out_features=1, hidden_layer_config=from_file["hidden_layer_nodes"],
-                      w0=from_file["w0"], ww=None, activation=from_file.get('activation', 'sine'))
+                      w0=from_file["w0"], ww=from_file.get("ww"), activation=from_file.get('activation', 'sine'))
         model.load_state_dict(torch.load(from_file["model_path"], weights_only=True))
     dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
     model.to(dev)
@@ -60,5 +60,5 @@ if __name__ == "__main__":
     generate_mc(None, cfg["gt_mode"], cfg.get("device", 0), cfg["nsamples"], cfg["output_path"], cfg.get("alpha"),
                 cfg["algorithm"], from_file={"w0": cfg["w0"], "model_path": cfg["model_path"],
                                              "hidden_layer_nodes": cfg["hidden_layer_nodes"],
-                                             "activation": cfg.get("activation", "sine")},
+                                             "activation": cfg.get("activation", "sine"), "ww": cfg.get("ww")},
                 luts=cfg.get("luts_path"))

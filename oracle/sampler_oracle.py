@@ -82,4 +82,5 @@ def sample_batch(tri, pc_pos, pc_nrm, n_on, n_far, n_near, seed, step, rank=0, w
         sdf = np.concatenate([np.zeros(len(x_on)), cloud_distance(far, pc_pos), np.abs(off)]).astype(np.float32)
     else:
         sdf = np.concatenate([np.zeros(len(x_on)), mesh_distance(far, tri), mesh_distance(near, tri)]).astype(np.float32)
+    sdf[len(x_on):] = np.maximum(sdf[len(x_on):], np.float32(1.17549435e-38))   # off-surface samples never carry the on-surface marker sdf == 0 (dudf_sample.hip)
     return x, nrm, sdf.reshape(-1, 1)

@@ -244,16 +244,26 @@ def test_train_cli_loop_runs(tmp_path):
     assert (base / "params.json").exists()
 
 
-def test_train_cli_post_training_artefacts(tmp_path):
+@pytest.mark.parametrize("ww", [None, 10])
+def test_train_cli_post_training_artefacts(tmp_path, ww):
     """reference train.py:403-446: with `resolution != 0` the run ends with the field slice of the best model
-    (generate_df) and its mesh (generate_mc; the CAP-UDF half of algorithm 'both'), here on the device."""
+    (generate_df) and its mesh (generate_mc; the CAP-UDF half of algorithm 'both'), here on the device.
+    ww != w0 (reference train.py:322): the periodic-checkpoint meshes come from a network with the config's hidden-layer frequency
+    (they were built with ww = w0)."""
     import train
     cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "train_synth_eikonal.json")))
     cfg.update({"num_epochs": 5, "s1_epochs": 3, "warmup_epochs": 1, "batch_size": 3000, "resolution": 24, "epochs_to_checkpoint": 2,
                 "checkpoint_path": str(tmp_path), "experiment_name": "t",
-                "network": {"hidden_layer_nodes": [64] * 4, "w0": 30, "pretrained_dict": "None"}})
+                "network": dict({"hidden_layer_nodes": [64] * 4, "w0": 30, "pretrained_dict": "None"}, **({"ww": ww} if ww else {}))})
     t, meshes = train.setup_train(cfg, 0)
     rec = tmp_path / "t" / "reconstructions"
+    # the mesh of a periodic checkpoint = the mesh of that checkpoint's file in a network of the CONFIG's frequencies
+    from generate_mc import generate_mc
+    from src.model import SIREN
+    m = SIREN(n_in_features=3, n_out_features=1, hidden_layer_config=[64] * 4, w0=30, ww=ww)
+    m.load_state_dict(torch.load(tmp_path / "t" / "models" / "model_2.pth", weights_only=True))
+    generate_mc(m, "tanh", 0, 24, str(tmp_path / "chk.obj"), alpha=cfg["alpha"], algorithm="cap")
+    assert open(tmp_path / "chk.obj").read() == open(rec / "mc_mesh_2_CAP.obj").read()
     # periodic checkpoints carry their mesh (reference train.py:253-268: generate_mc at every `epochs_to_checkpoint`)
     for ep in (2, 4):
         assert (tmp_path / "t" / "models" / f"model_{ep}.pth").exists() and (rec / f"mc_mesh_{ep}_CAP.obj").exists(), ep

@@ -51,16 +51,16 @@ def test_child_exit_code_comes_back():
 @pytest.mark.gpu
 @pytest.mark.parametrize("gpus,points", [(2, 20000), (8, 12500)])
 def test_bench_gpus_n_as_typed_on_one_gpu(gpus, points):
-    env = dict(os.environ, DUDF_TEST_SHARE_GPU="1")
+    env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DUDF_BENCH_DRY_LAUNCH"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-config3", "--points", str(points)], env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+                        "--no-config3", "--points", str(points), "--share-device"], env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == gpus and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["n_gpus"] == gpus and d["steps"] == 3 and d["scaling"] == "weak" and d["share_device"] is True
     assert d["config"]["global_batch"] == gpus * points and d["value"] > 0
     assert d["collectives"] in ("staggered", "fused")
     ph = d["phases_ms"]

@@ -171,7 +171,8 @@ def _train(dataset, model, device, config, schedule):
                                 output_path=osp.join(log_path, "reconstructions", f'mc_mesh_{epoch}.obj'), alpha=config['alpha'],
                                 algorithm='both', from_file={'w0': net["w0"], 'model_path': ckpt,
                                                              'hidden_layer_nodes': net["hidden_layer_nodes"],
-                                                             'activation': net.get('activation', 'sine')},
+                                                             'activation': net.get('activation', 'sine'),
+                                                             'ww': net.get('ww')},           # the hidden layers' own frequency, if the config has one (reference train.py:322)
                                 luts=config.get("luts_path"))
             elif config.get("save_every_epoch", True):
                 torch.save(snapshot_state(snap), osp.join(log_path, "models", "model_current.pth"))
@@ -312,17 +313,14 @@ def setup_train(parameter_dict, cuda_device):
         raise SystemExit("train.py: no GPU visible; the HIP training path has no CPU fallback")
     rank = world = None
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        # DUDF_TEST_SHARE_GPU=1: functional check of the N>1 path on a ONE-GPU box (every rank on device 0, gloo instead
-        # of RCCL, which refuses two ranks on one device).  Never set for a measurement.
-        share = os.environ.get("DUDF_TEST_SHARE_GPU") == "1"
-        cuda_device = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(cuda_device)
-        if not _dist():
+        if _dist():
+            # a launcher initialised torch.distributed (and chose this process's device) already: adopt both
+            cuda_device = torch.cuda.current_device()
+        else:
+            cuda_device = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(cuda_device)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if share:
-                torch.distributed.init_process_group("gloo")
-            else:
-                torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", cuda_device))
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", cuda_device))
         rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
     device = torch.device("cuda", int(cuda_device))
     seed = 123
