@@ -71,6 +71,25 @@ class TrainEngine:
         if not 8 <= int(self.wgrad_max_workgroups) <= 256:
             raise ValueError(f"wgrad_max_workgroups must be 8..256 (one workgroup per CU at most); got {self.wgrad_max_workgroups}")
         self._set_cap = getattr(self.ops, "set_wgrad_max_workgroups", None) if ops is None else None
+        if self._dist:
+            self._prime_collectives()
+
+    def _prime_collectives(self):
+        """Everything a step's collectives create lazily — the backend's communicator and streams, their hardware queues, pinned staging
+        buffers — exists before the first step: one round of the step's own all-reduces over the (still zero) flat buffer, then a
+        device-wide wait.  A queue created in the middle of step 0 makes the driver rebuild the GPU's run list under the running
+        weight-gradient GEMM; here it happens while nothing of ours is in flight."""
+        if self.collectives == "staggered" and hasattr(self.ops, "weight_gradient"):     # (the path loss_and_grad takes: `overlapped`)
+            L = self.cfg.n_hidden_layers
+            sl = self.ops.layer_slices(self.cfg)
+            cuts = [(sl[b][0], sl[e - 1][1]) for b, e in self._layer_groups(L)] + [(sl[0][0], sl[0][1]), (sl[L][0], self.flat.numel())]
+            works = [torch.distributed.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True) for lo, hi in cuts]
+            for w in works:
+                w.wait()
+        else:
+            torch.distributed.all_reduce(self.flat, group=self.pg)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def _allreduce(self, t):
         if self._dist:

@@ -46,8 +46,16 @@ class Adam(torch.optim.Adam):
         self._row = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def replayed(self, n=1):
-        """A captured graph containing `step()` was replayed n times."""
-        self._t += n
+        """A captured graph containing `step()` was replayed n times.  The replay took its learning rate from the device table: the
+        host-side view has to agree with it (a scheduler or a user editing `param_groups` mid-run would otherwise be ignored silently)."""
+        for _ in range(n):
+            k = self._t - self._sched_t0
+            if self._sched_lrs is None or k >= len(self._sched_lrs):
+                raise RuntimeError(f"diffudf_amd.optim.Adam: replay of step {k} past a schedule of {0 if self._sched_lrs is None else len(self._sched_lrs)}")
+            if self.param_groups[0]["lr"] != self._sched_lrs[k]:
+                raise RuntimeError(f"diffudf_amd.optim.Adam: param_groups lr {self.param_groups[0]['lr']} != scheduled {self._sched_lrs[k]} at replayed step {k} "
+                                   "(under use_schedule the learning rates come from the table)")
+            self._t += 1
 
     def _flat_views(self):
         """(theta, dtheta) if the fast path applies right now, else None."""

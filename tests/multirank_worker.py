@@ -47,15 +47,6 @@ def run_engine(case, out):
     assert eng.world == world and eng._dist == (world > 1 or rccl1)
     if rccl1 and eng.collectives == "staggered":
         assert eng.wgrad_max_workgroups == 240
-    if os.environ.get("DUDF_TEST_WARMUP") and world > 1:          # (experiment, round 6) every stream / HSA queue / pinned buffer of the collectives exists before step 0
-        scratch = torch.zeros_like(eng.flat)
-        cuts = [0, 1024, 132608, 329984, 461568, scratch.numel()]
-        for _ in range(int(os.environ["DUDF_TEST_WARMUP"])):
-            works = [torch.distributed.all_reduce(scratch[a:b], async_op=True) for a, b in zip(cuts[:-1], cuts[1:])]
-            for wk in works:
-                wk.wait()
-        torch.cuda.synchronize()
-        torch.distributed.barrier()
     hist, first_grad = [], None
     # (test plumbing) what went INTO and came OUT of every collective, per rank and step.  Always: two-number digests (sum, sum of
     # magnitudes, in double, computed on the device right in front of the collective — no sync), written to <out>.rank<r>.json so that a

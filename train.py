@@ -30,10 +30,12 @@ import os
 import os.path as osp
 import random
 import time
+import weakref
 
 import numpy as np
 import torch
 
+from diffudf_amd import hip_ops
 from diffudf_amd.dataset import PointCloud, SyntheticPointCloud
 from diffudf_amd.loss_functions import loss_siren, loss_s1, loss_s2
 from diffudf_amd.model import SIREN
@@ -222,7 +224,8 @@ def _train(dataset, model, device, config, schedule):
     GRAPH_WARMUP = 3
     plan = [schedule(e) for e in range(epochs)]
     use_graph = (bool(config.get("hip_graph", True)) and device.type == "cuda" and not (_dist() and torch.distributed.get_world_size() > 1)
-                 and hasattr(optim, "use_schedule") and hasattr(dataset, "use_device_step"))
+                 and hasattr(optim, "use_schedule") and getattr(optim, "_model", None) is not None      # (the flat fast path: use_schedule needs it)
+                 and hasattr(dataset, "use_device_step"))
     graphs = {}
     if use_graph:
         lr0 = optim.param_groups[0]['lr']
@@ -254,8 +257,15 @@ def _train(dataset, model, device, config, schedule):
                 st["graph"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(st["graph"]):
                     st["vals"], st["names"] = one_step(loss_fn, loss_weights, extra)
+                # the graph holds raw pointers into the training workspace(s) of hip_ops' cache: remember which, and never replay
+                # into one that has been evicted since (a schedule that comes back to an earlier phase after the batch layout changed)
+                st["ws"] = [weakref.ref(w) for w in hip_ops._ws_cache.values()]
                 st["graph"].replay()                   # a capture records, it does not run: this IS the step just counted by one_step
                 vals, names = st["vals"], st["names"]
+            elif any(r() is None or r() not in hip_ops._ws_cache.values() for r in st["ws"]):
+                st.update({"graph": None, "eager": GRAPH_WARMUP - 1})       # its workspace is gone: one eager step, then capture again
+                vals, names = one_step(loss_fn, loss_weights, extra)
+                st["eager"] += 1
             else:
                 st["graph"].replay()
                 optim.replayed(); dataset.replayed()
