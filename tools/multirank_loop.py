@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--n-global", type=int, default=100000)
     ap.add_argument("--ones", type=int, default=3, help="1-rank runs made first (they must agree with each other)")
     ap.add_argument("--variants", default="", help="';'-separated environment settings cycled run by run on the SAME box, e.g. "
-                    "'base;DUDF_TEST_WARMUP=3;GPU_MAX_HW_QUEUES=1' (A/B/C interleaved: boxes differ, calls are not comparable)")
+                    "'GPU_MAX_HW_QUEUES=4;GPU_MAX_HW_QUEUES=2;GPU_MAX_HW_QUEUES=4 DUDF_TEST_OPTS=sweep_family=0,wgrad_family=1' (A/B/C interleaved: boxes differ, calls are not comparable)")
     a = ap.parse_args()
     import test_multirank_gpu as T
     os.environ["DUDF_TEST_NGLOBAL"] = str(a.n_global)
@@ -156,7 +156,7 @@ def main():
     for run in range(a.runs):
         var = variants[run % len(variants)]
         os.environ.clear(); os.environ.update(base_env)
-        for kv in var.split(","):
+        for kv in var.split():                                   # whitespace-separated NAME=VALUE settings of one variant
             if "=" in kv:
                 k, v = kv.split("=", 1)
                 os.environ[k] = v
