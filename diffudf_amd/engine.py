@@ -23,17 +23,14 @@ LOSS_S1, LOSS_S2, LOSS_SIREN = 0, 1, 2
 
 class TrainEngine:
     def __init__(self, hidden, theta, w0=30.0, process_group=None, betas=(0.9, 0.999), eps=1e-8, ops=None,
-                 collectives=None, ww=None, wgrad_max_workgroups=None, _force_collectives=False):
+                 collectives=None, ww=None, wgrad_max_workgroups=None):
         """`ops` defaults to the HIP kernels.  It is a parameter only so that the CPU/gloo tests can drive the
         distributed bookkeeping below with a stand-in compute backend; nothing in the product passes it.
         `collectives` (N > 1 ranks): "staggered" = five all-reduces per step (three hidden-layer groups, each behind the
         weight-gradient GEMM of the next group, + the two thin layers), "fused" = ONE all-reduce of the flat
         [dtheta | terms] buffer after the whole backward; default "staggered" (bench.py --collectives).  Both give the same
         numbers; which is faster on xGMI is a latency question the first hardware run has to answer —
-        `phase_times()` is there to read it off.
-        `_force_collectives` (tests only, like `ops`): take the N > 1 code path — the 240-workgroup cap, the async all-reduces of
-        the layer groups, Adam per group — in a world of ONE rank, so that a one-GPU box can run it over the real RCCL backend
-        (tests/test_multirank_gpu.py::test_one_rank_over_rccl; RCCL refuses two ranks on one device)."""
+        `phase_times()` is there to read it off."""
         self.ops = _hip_ops if ops is None else ops
         self.cfg = self.ops.make_cfg(hidden, w0) if ww is None else self.ops.make_cfg(hidden, w0, ww=ww)
         n_theta = self.ops.theta_count(self.cfg)
@@ -62,7 +59,7 @@ class TrainEngine:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
-        self._dist = self.world > 1 or (bool(_force_collectives) and torch.distributed.is_available() and torch.distributed.is_initialized())
+        self._dist = self.world > 1
         # staggered collectives: leave 16 CUs to the RCCL kernels that overlap the weight-gradient GEMMs; otherwise the whole
         # chip.  The cap is a process-wide option of the library, so THIS engine sets it right in front of its own
         # weight-gradient launches (loss_and_grad) — another engine of the process may want another value.

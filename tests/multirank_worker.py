@@ -43,10 +43,15 @@ def run_engine(case, out):
         hip_ops.set_option(k, int(v))
     dev = torch.device("cuda", 0)
     theta = torch.from_numpy(synth.flatten_params(synth.siren_params(HIDDEN, seed=123))).to(dev)
-    eng = TrainEngine(HIDDEN, theta, collectives=os.environ.get("DUDF_TEST_COLLECTIVES") or None, _force_collectives=rccl1)   # (test plumbing: the worker's own variable)
+    eng = TrainEngine(HIDDEN, theta, collectives=os.environ.get("DUDF_TEST_COLLECTIVES") or None)   # (test plumbing: the worker's own variable)
+    if rccl1:
+        # a world of ONE rank takes the engine's N > 1 code path: this test flips the engine's own switch and sets what its constructor
+        # would have set for a larger world (the product has no such option)
+        eng._dist = True
+        if eng.collectives == "staggered":
+            eng.wgrad_max_workgroups = 240
+        eng._prime_collectives()
     assert eng.world == world and eng._dist == (world > 1 or rccl1)
-    if rccl1 and eng.collectives == "staggered":
-        assert eng.wgrad_max_workgroups == 240
     hist, first_grad = [], None
     # (test plumbing) what went INTO and came OUT of every collective, per rank and step.  Always: two-number digests (sum, sum of
     # magnitudes, in double, computed on the device right in front of the collective — no sync), written to <out>.rank<r>.json so that a

@@ -8,9 +8,9 @@ launcher (tests/multirank_worker.py initialises the process group; train.py adop
 One hardware queue per process (GPU_MAX_HW_QUEUES=1).  Round 5's driver run of the 8-rank test was red; round 6 traced it
 (tools/multirank_loop.py, profiles/r06_*): with the HIP runtime's default of four hardware queues per process, eight
 processes oversubscribe the chip's 24 user-queue slots, the hardware scheduler time-slices the run list, and on this platform a
-queue that comes back then SKIPS one dispatch on one XCD and REPLAYS it on the neighbouring one — a `hipMemsetAsync` that left the
+queue that comes back then SKIPS one dispatch on one XCD and REPLAYS it on another — a `hipMemsetAsync` that left the
 4 KiB chunks == k (mod 8) of its range stale, an Adam update applied twice to 1/8 of theta and not at all to another 1/8 — 8 of 120
-runs, against 0 of 120 with one queue per process, interleaved on the same box.  One process per GPU (the real multi-GPU run) never
+runs, against 0 of 120 with one queue per process (and 0 of 100 with two), interleaved on the same box.  One process per GPU (the real multi-GPU run) never
 oversubscribes.
 
 A failing leg is run a second time and the per-rank digests of both runs (what every rank put into and got out of every collective,

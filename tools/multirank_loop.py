@@ -38,7 +38,7 @@ def layer_of(lo, H=256, L=8):
     return [nm for a, b, nm in bounds if a <= lo < b][0]
 
 
-SAVE = os.path.join(REPO, "gpurun_out", "r06_bad")
+SAVE = os.environ.get("DUDF_LOOP_SAVE")            # a directory: keep the offending slices / thetas of bad runs as .npz (1-5 MB each)
 
 
 def pattern(got, want, lo, hi, H=256):
