@@ -51,6 +51,32 @@ __global__ __launch_bounds__(512) void spin_scratch_kernel(unsigned* err, long l
     if (s == 12345.678f) atomicAdd(err + 1, 1u);
 }
 
+// Growing scratch needs, like a training step's first kernels (reverse sweep 20 B, adjoint forward sweep 60 B, thin-layer gradients 64 B, f32
+// sweeps 232 B per lane): every kernel that needs more scratch than its queue has makes the runtime re-size the queue's scratch.
+template <int NF>
+__global__ __launch_bounds__(512) void scratch_n_kernel(unsigned* err, long long cycles, int stride) {
+    volatile float priv[NF];
+    for (int i = 0; i < NF; ++i) priv[i] = (float)(threadIdx.x * NF + i);
+    const long long t0 = clock64();
+    int j = threadIdx.x % NF;
+    float s = 0.f;
+    while (clock64() - t0 < cycles) { s += priv[j]; priv[j] = priv[j] + 0.f; j = (j + stride) % NF; }
+    unsigned bad = 0;
+    for (int i = 0; i < NF; ++i) bad += (priv[i] != (float)(threadIdx.x * NF + i));
+    if (bad) atomicAdd(err, bad);
+    if (s == 12345.678f) atomicAdd(err + 1, 1u);
+}
+extern "C" int scratch_n_launch(unsigned* err, int which, int blocks, long long cycles, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (which) {
+        case 0: hipLaunchKernelGGL(scratch_n_kernel<6>, dim3(blocks), dim3(512), 0, st, err, cycles, 5); break;
+        case 1: hipLaunchKernelGGL(scratch_n_kernel<16>, dim3(blocks), dim3(512), 0, st, err, cycles, 5); break;
+        case 2: hipLaunchKernelGGL(scratch_n_kernel<24>, dim3(blocks), dim3(512), 0, st, err, cycles, 5); break;
+        default: hipLaunchKernelGGL(scratch_n_kernel<60>, dim3(blocks), dim3(512), 0, st, err, cycles, 7); break;
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" int spin_scratch_launch(unsigned* err, int blocks, long long cycles, int lds_bytes, void* stream) {
     static int cur = -1;
     if (lds_bytes != cur) {

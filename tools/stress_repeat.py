@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--max-report", type=int, default=6)
     ap.add_argument("--side-streams", type=int, default=0, help="N high-priority side streams that pick up behind every weight-gradient group, like the "
                     "async gloo all-reduces of the staggered engine path: wait for the compute stream, D2H + H2D of the group's slice through pinned memory")
+    ap.add_argument("--churn", type=int, default=0, help="extra processes that keep starting short-lived GPU processes (import, load the library, three small "
+                    "steps on four streams, exit) while the P stress processes run: queue creation / destruction and code-object loads by OTHER processes")
     ap.add_argument("--sync-phases", type=int, default=0, help="1: compare the workspace after every phase, not only after the step")
     return ap.parse_args()
 
@@ -233,6 +235,15 @@ def main():
     a = parse()
     if a.child >= 0:
         sys.exit(child(a))
+    stop = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"stress_stop_{os.getpid()}")
+    churn_src = ("import os, sys, subprocess\n"
+                 "n = 0\n"
+                 "while not os.path.exists(sys.argv[1]):\n"
+                 f"    subprocess.run([sys.executable, {os.path.abspath(__file__)!r}, '--child', '0', '--procs', '1', '--reps', '2', '--n-global', '4000', '--side-streams', '4', '--presteps', '1'], "
+                 "stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)\n"
+                 "    n += 1\n"
+                 "print('[churn] generations:', n, flush=True)\n")
+    churners = [subprocess.Popen([sys.executable, "-c", churn_src, stop], cwd=REPO) for _ in range(a.churn)]
     procs = []
     for r in range(a.procs):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -240,6 +251,10 @@ def main():
     rc = 0
     for p in procs:
         rc |= p.wait()
+    open(stop, "w").close()
+    for c in churners:
+        c.wait()
+    os.unlink(stop)
     print("STRESS", "FAIL" if rc else "OK", " ".join(sys.argv[1:]), flush=True)
     sys.exit(1 if rc else 0)
 
