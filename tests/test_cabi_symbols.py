@@ -98,3 +98,26 @@ def test_stash_arrays_sit_on_the_cache_line_grid():
             assert vals[8] >= 16 * n and vals[9] == vals[8] * hidden // 4
             assert vals[8] % (1 << 15) != 0, "row stride a large power of two: rows share HBM channels"
     assert lib.dudf_debug_stash_layout(ctypes.byref(_lib.NetCfg(3, 8, 100, 30.0)), 10, 0, out) != 0
+
+
+def test_replayed_steps_follow_the_schedule_on_the_host():
+    """`diffudf_amd.optim.Adam.replayed()`: a graph replay takes its learning rate from the device table; the host-side view —
+    `param_groups[0]['lr']`, what a scheduler or a checkpoint reads — has to agree with it at every replayed step, and a replay past the
+    end of the schedule is an error, not a silent no-op.  Host only: no kernel is launched."""
+    import pytest
+    from diffudf_amd.model import SIREN
+    from diffudf_amd.optim import Adam
+    m = SIREN(n_in_features=3, n_out_features=1, hidden_layer_config=[32] * 2, w0=30)
+    opt = Adam(m.parameters(), lr=1e-4, model=m)
+    opt.use_schedule([1e-4, 1e-4, 5e-5])
+    opt.replayed()
+    opt.param_groups[0]["lr"] = 2e-4                     # somebody edits the rate behind the table's back
+    with pytest.raises(RuntimeError, match="scheduled"):
+        opt.replayed()
+    opt.param_groups[0]["lr"] = 1e-4
+    opt.replayed()
+    opt.param_groups[0]["lr"] = 5e-5
+    opt.replayed()
+    assert opt._t == 3
+    with pytest.raises(RuntimeError, match="past a schedule"):
+        opt.replayed()
