@@ -320,7 +320,7 @@ __device__ __forceinline__ void sweep_tile_b(const SweepArgs& a, const int g_fir
         // on their own path (and R, E come back rounded to 16 significant bits): a column whose bound sits an ulp under a power of two
         // could hand the fixed-point stash a value a grid step outside [-1, 1] 2^E, which fx24_pack would wrap to +5 2^E.
         // Once per layer and column, not per value; costs a bit of the column's precision in 0.14 % of the scale decisions.
-        bound *= 1.0009765625f;
+        bound *= DUDF_FX_HEADROOM;
         unsigned E = (__float_as_uint(bound) >> 23) & 255u;    // bound < 2^(E - 126)
         E = E < 27u ? 27u : (E > 250u ? 250u : E);             // all-zero (padding) columns, infinities: any finite scale will do
         sb = __uint_as_float((268u - E) << 23);                // 2^(15 - (E - 126))
@@ -875,7 +875,7 @@ __device__ __forceinline__ void sweep_tile_oct(const SweepArgs& a, const int g, 
             float mm = 0.f;
 #pragma unroll
             for (int w = 0; w < NWB; ++w) mm = fmaxf(mm, cmx[w * 16 + li]);
-            const float bound = (a.w0 * (mm * unscale) + eb) * 1.0009765625f;      // (2^-10 of head room: see set_scale)
+            const float bound = (a.w0 * (mm * unscale) + eb) * DUDF_FX_HEADROOM;   // (2^-10 of head room: see set_scale)
             unsigned E = (__float_as_uint(bound) >> 23) & 255u;
             E = E < 27u ? 27u : (E > 250u ? 250u : E);
             sb = __uint_as_float((268u - E) << 23);
@@ -1998,3 +1998,12 @@ int dudf_launch_pack_bf16(const DudfLayout& lo, const float* theta, float* ws, h
     if (lo.H == 512) return pack_b<512>(lo, theta, ws, st);
     return 0;
 }
+
+#if DUDF_FX_CHECK
+// debug build only (not part of the C ABI): granules the fixed-point packers would have wrapped since the last reset — [0] S/Q/A/Z, [1] C
+extern "C" int dudf_dbg_fx_violations(unsigned* out2, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_dudf_fx_bad), 2 * sizeof(unsigned));
+    if (e == hipSuccess && reset) { const unsigned z[2] = {0u, 0u}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_dudf_fx_bad), z, sizeof(z)); }
+    return (int)e;
+}
+#endif

@@ -140,7 +140,23 @@ __device__ __forceinline__ f32x4 p24_unpack_raw(const f32x4 r) { return p24_unpa
 // (t's patterns are 0x40000000 | u) and c = t - 3 is exact.  Absolute error <= 2^-23 = 1.2e-7 — the size of the polynomial
 // pair's own error (9.4e-8) — where a 24-bit FLOAT (the "p24" arrays) would lose 2^-17 of every value; the 12-step beetle
 // trajectory does not see it (profiles/r04_cround.txt: 2^-22 and 2^-23 grids both within 5e-7, like fp32).
+// Debug build (-DDUDF_FX_CHECK=1, tools/fx_check.py): count the granules whose values the two fixed-point packers would WRAP
+// (a value outside [-1, 1] of its grid reads back as ~ +5) — the precondition `set_scale`'s bound and |cos| <= 1 have to guarantee.  The counter is
+// read by dudf_dbg_fx_violations (dudf_sweep_bf16.hip, debug build only); the branch is never taken unless the invariant breaks.
+#ifndef DUDF_FX_CHECK
+#define DUDF_FX_CHECK 0
+#endif
+#ifndef DUDF_FX_HEADROOM
+#define DUDF_FX_HEADROOM 1.0009765625f      // factor on the column bound before its exponent is taken (set_scale); a debug build with < 1 is the positive control of the counters
+#endif
+#if DUDF_FX_CHECK
+static __device__ unsigned g_dudf_fx_bad[2];          // [0] fx24_pack: |v fs| > 1, [1] c24_pack: |c| > 1
+#define DUDF_FX_COUNT(i, cond) do { if (cond) atomicAdd(&g_dudf_fx_bad[i], 1u); } while (0)
+#else
+#define DUDF_FX_COUNT(i, cond) do { } while (0)
+#endif
 __device__ __forceinline__ dudf_u3 c24_pack(const f32x4 c) {
+    DUDF_FX_COUNT(1, fabsf(c[0]) > 1.f || fabsf(c[1]) > 1.f || fabsf(c[2]) > 1.f || fabsf(c[3]) > 1.f);
     const unsigned u0 = __float_as_uint(c[0] + 3.0f), u1 = __float_as_uint(c[1] + 3.0f),
                    u2 = __float_as_uint(c[2] + 3.0f), u3 = __float_as_uint(c[3] + 3.0f);
     // values 0-2 in the low three bytes of a dword each, value 3 spread over the three top bytes: three of four values come back
@@ -168,6 +184,7 @@ __device__ __forceinline__ f32x4 c24_unpack(const dudf_u3 d) {
 // 4 (2^-17 of every value) the noise on a column's dominant entries is 2^-6 of that.  The reader multiplies t - 3 by 2^E, which
 // the sweep leaves per layer and column in a side array (SweepArgs::fxs).  |h| = |sin| <= 1 in the plain columns' forward sweep: fs = 1.
 __device__ __forceinline__ dudf_u3 fx24_pack(const f32x4 v, const float fs) {
+    DUDF_FX_COUNT(0, fabsf(v[0] * fs) > 1.f || fabsf(v[1] * fs) > 1.f || fabsf(v[2] * fs) > 1.f || fabsf(v[3] * fs) > 1.f);
     const unsigned u0 = __float_as_uint(__builtin_fmaf(v[0], fs, 3.0f)), u1 = __float_as_uint(__builtin_fmaf(v[1], fs, 3.0f)),
                    u2 = __float_as_uint(__builtin_fmaf(v[2], fs, 3.0f)), u3 = __float_as_uint(__builtin_fmaf(v[3], fs, 3.0f));
     dudf_u3 d;
