@@ -1073,256 +1073,6 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
     wgrad_hidden_bf16p_body<H, VAR, 1, 1>(a);
 }
 
-// ---- ONE wave per SIMD (round 6, option wgrad_family = 3): the same GEMM on FOUR waves of 128 x 128 outputs -----------------
-// The shipped kernel above runs two waves per SIMD that take turns on the matrix pipe; measured on its own instruction stream (§3.3) the
-// hand-over costs 0.09 ms and the 96 KiB of fragment reads per stage another 0.09.  Here a workgroup is 4 waves (2 x 2, one per SIMD, 4 x 4 tiles
-// of 32 x 32 = 256 accumulation registers each): no partner, 64 KiB of fragment reads per stage, and the split of the NEXT stage's operands
-// is dealt out between this stage's four MFMA groups of ONE in-order instruction stream.  Same operands (24-bit fixed-point tile-major
-// granules + column scales), same [column][feature] fp16 image and transposed fragment reads, same products, same output atomics.
-// Two image buffers and one workgroup barrier per stage: the four waves do identical work and drift little.
-typedef unsigned dudf_u3w __attribute__((ext_vector_type(3)));
-struct Raw4 { dudf_u3w x0, x1, x2, x3, y0, y1, y2, y3; float sx, sy; };     // one stage of this wave's share: 4 + 4 granules and the two column scales
-template <int DBG4>
-__device__ __forceinline__ void wgrad4_body(const WgradArgs& a) {
-    constexpr int MT = 4, NTL = 4;
-    constexpr int ROWB = 576, PIECEB = 16 * ROWB, OPERB = 2 * PIECEB, BUFB = 2 * OPERB;      // 36 KiB per image
-    extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave >> 1, wi = wave & 1;
-    const int q = lane >> 4, li = lane & 15;
-    const int j = (int)blockIdx.x + a.j0, by = (int)blockIdx.y, nsplit = (int)gridDim.y;
-    const int steps16 = a.steps_total * (KT / KB);
-    const int s0 = (int)((int64_t)steps16 * by / nsplit), s1 = (int)((int64_t)steps16 * (by + 1) / nsplit);
-    const bool clk_on = a.clk != nullptr && blockIdx.x == 0 && by == 0;
-    const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    f32x16 acc[MT][NTL];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NTL; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-    const int64_t lstride = a.stash_layer / 4 * 3;                       // floats per layer of a 24-bit array
-    const char* X[2] = {reinterpret_cast<const char*>(a.Q + (int64_t)(j + 1) * lstride), reinterpret_cast<const char*>(a.Z + (int64_t)(j + 1) * lstride)};
-    const char* Y[2] = {reinterpret_cast<const char*>(a.A + (int64_t)j * lstride), reinterpret_cast<const char*>(a.S + (int64_t)j * lstride)};
-    const float* FX[2] = {a.fxQ + (int64_t)(j + 1) * a.np, a.fxZ + (int64_t)(j + 1) * a.np};
-    const float* FY[2] = {a.fxA + (int64_t)j * a.np, a.fxS + (int64_t)j * a.np};
-    const int npair = a.have_g ? 2 : 1;
-    const int nit = npair * (s1 - s0);
-    auto pair_of = [&](int it) { return a.have_g ? (it & 1) : 1; };
-    auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
-    // layer scales of the fp16 split (as in the kernel above): each operand's largest element below 2^15, both pairs at one product scale 2^P
-    float scX[2], scY[2], inv_p;
-    {
-        const int eq = dudf_exp_above(a.amax[0 * a.L + j + 1]), eA = dudf_exp_above(a.amax[1 * a.L + j]);
-        const int ez = dudf_exp_above(a.amax[2 * a.L + j + 1]);
-        const int esh = dudf_exp_above(a.amax[3 * a.L + j]);
-        const int es = esh > 1 ? esh : 1;
-        const int P1l = 30 - eq - eA, P2l = 30 - ez - es;
-        const int P = (a.have_g && P1l < P2l) ? P1l : P2l;
-        scX[0] = dudf_pow2(15 - eq - (P1l - P)); scY[0] = dudf_pow2(15 - eA);
-        scX[1] = dudf_pow2(15 - ez - (P2l - P)); scY[1] = dudf_pow2(15 - es);
-        inv_p = dudf_pow2(-P);
-    }
-    // producer role: wave w stages feature tiles 4 w .. 4 w + 3 of BOTH operands; lane = (q, li) holds features 16 T + 4 q .. + 3 of column li
-    const int64_t ngrp = a.np >> 4;
-    const unsigned vstep = (unsigned)(ngrp * 768);                       // (the launcher keeps a layer of a 24-bit array below 2^32 bytes)
-    const unsigned voff0 = (unsigned)(lane * 12) + (unsigned)(4 * wave) * vstep;
-    const unsigned li4 = (unsigned)li * 4u;
-    const int sw = (li >> 1) & 7;
-    const int w_even = li * ROWB + 128 * wave + 8 * (q ^ sw), w_odd = li * ROWB + 128 * wave + 8 * ((4 + q) ^ sw);
-    const float bm_quad = ((lane & 3) == 0) ? 1.f : 0.f;
-    float bsum[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[t][e] = 0.f;
-    // ordinary loads (prologue, last stages) ...
-    auto load_plain = [&](int it, Raw4& r) {
-        const int pr = pair_of(it);
-        const int64_t st = step_of(it);
-        const char* xs = X[pr] + st * 768 + voff0;
-        const char* ys = Y[pr] + st * 768 + voff0;
-        auto ld = [](const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const dudf_u3w*>(p)); };
-        r.x0 = ld(xs); r.x1 = ld(xs + vstep); r.x2 = ld(xs + 2 * (size_t)vstep); r.x3 = ld(xs + 3 * (size_t)vstep);
-        r.y0 = ld(ys); r.y1 = ld(ys + vstep); r.y2 = ld(ys + 2 * (size_t)vstep); r.y3 = ld(ys + 3 * (size_t)vstep);
-        r.sx = FX[pr][st * KB + li];
-        r.sy = FY[pr][st * KB + li];
-    };
-    // ... and the steady state's: inline asm + hand-counted vmcnt (a compiler-visible load makes hipcc drain EVERYTHING in flight — vmcnt(0) —
-    // at the first use of any loaded register; these ten are the only vector-memory instructions of the hot loop)
-    constexpr int kSet = 10;
-    auto load_asm = [&](int it, Raw4& r) {
-        const int pr = pair_of(it);
-        const int64_t st = step_of(it);
-        auto sgpr64 = [](const void* p) {
-            const uint64_t g = (uint64_t)(size_t)p;
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)g), hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
-            return ((uint64_t)hi << 32) | lo;
-        };
-        const uint64_t xb = sgpr64(X[pr] + st * 768), yb = sgpr64(Y[pr] + st * 768);
-        const uint64_t fxb = sgpr64(FX[pr] + st * KB), fyb = sgpr64(FY[pr] + st * KB);
-        asm volatile("global_load_dwordx3 %0, %4, %8 nt\n\tglobal_load_dwordx3 %1, %5, %8 nt\n\t"
-                     "global_load_dwordx3 %2, %6, %8 nt\n\tglobal_load_dwordx3 %3, %7, %8 nt"
-                     : "=&v"(r.x0), "=&v"(r.x1), "=&v"(r.x2), "=&v"(r.x3)
-                     : "v"(voff0), "v"(voff0 + vstep), "v"(voff0 + 2 * vstep), "v"(voff0 + 3 * vstep), "s"(xb) : "memory");
-        asm volatile("global_load_dwordx3 %0, %4, %8 nt\n\tglobal_load_dwordx3 %1, %5, %8 nt\n\t"
-                     "global_load_dwordx3 %2, %6, %8 nt\n\tglobal_load_dwordx3 %3, %7, %8 nt"
-                     : "=&v"(r.y0), "=&v"(r.y1), "=&v"(r.y2), "=&v"(r.y3)
-                     : "v"(voff0), "v"(voff0 + vstep), "v"(voff0 + 2 * vstep), "v"(voff0 + 3 * vstep), "s"(yb) : "memory");
-        asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4" : "=&v"(r.sx), "=&v"(r.sy) : "v"(li4), "s"(fxb), "s"(fyb) : "memory");
-    };
-    auto wait_set = [&](Raw4& r, auto younger) {         // this set has landed; `younger` loads issued after it stay in flight
-        asm volatile("s_waitcnt vmcnt(%10)" : "+v"(r.x0), "+v"(r.x1), "+v"(r.x2), "+v"(r.x3), "+v"(r.y0), "+v"(r.y1), "+v"(r.y2), "+v"(r.y3),
-                     "+v"(r.sx), "+v"(r.sy) : "n"(decltype(younger)::value));
-    };
-    // half a tile of one operand (values 2 h, 2 h + 1 of the lane's four): 24-bit fixed point -> value in the GEMM's scale -> fp16 hi / lo ->
-    // two 4-byte writes into row li of the [column][feature] image.  16 of these per stage: one in front of each tile's three MFMAs.
-    auto split_half = [&](int it, const Raw4& r, int k, int bsel) {
-        const int pr = pair_of(it);
-        const int T8 = k >> 1, hf = k & 1, oper = T8 >> 2, t = T8 & 3;
-        const dudf_u3w g = oper == 0 ? (t == 0 ? r.x0 : t == 1 ? r.x1 : t == 2 ? r.x2 : r.x3) : (t == 0 ? r.y0 : t == 1 ? r.y1 : t == 2 ? r.y2 : r.y3);
-        const float scl = (oper == 0 ? r.sx * scX[pr] : r.sy * scY[pr]);
-        const float m3 = -3.0f * scl;
-        const unsigned m = 0x00ffffffu, two = 0x40000000u;
-        unsigned ta, tb;
-        if (hf == 0) { ta = (g.x & m) | two; tb = (g.y & m) | two; }
-        else {
-            ta = (g.z & m) | two;
-            const unsigned y = __builtin_amdgcn_perm(g.y, g.x, 0x0c0c0703u);
-            tb = __builtin_amdgcn_perm(g.z, y, 0x0c070100u) | two;
-        }
-        const float v0 = __builtin_fmaf(__uint_as_float(ta), scl, m3), v1 = __builtin_fmaf(__uint_as_float(tb), scl, m3);
-        if (oper == 0) {
-            const float hs = ((int64_t)step_of(it) * KB < a.ncol_h) ? 1.f : 0.f;
-            const float bmask = (pr == 1 ? 1.f : 0.f) * (1.f + hs * (bm_quad - 1.f));
-            bsum[t][2 * hf] += bmask * v0; bsum[t][2 * hf + 1] += bmask * v1;
-        }
-        const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);
-        f32x2 rr;
-        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rr.x) : "v"(v0), "v"(h));
-        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rr.y) : "v"(v1), "v"(h));
-        const f16x2 l = __builtin_convertvector(rr, f16x2);
-        char* dst = ldsb + bsel * BUFB + oper * OPERB + ((t & 1) ? w_odd : w_even) + 64 * (t >> 1) + 4 * hf;
-        *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, h);
-        *reinterpret_cast<unsigned*>(dst + PIECEB) = __builtin_bit_cast(unsigned, l);
-    };
-    // consumer role: transposed fragment reads (as above)
-    const int c_k = 8 * (lane >> 5) + ((lane & 15) >> 2), c_u = 4 * ((lane >> 4) & 1) + (lane & 3);
-    const int c_t0 = c_k * ROWB + 8 * (c_u ^ ((c_k >> 1) & 7)), c_t1 = (c_k + 4) * ROWB + 8 * (c_u ^ (((c_k + 4) >> 1) & 7));
-    auto frag_tr = [&](const char* base) -> u32x4 {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + c_t0)));
-        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + c_t1)));
-        return u32x4{lo.x, lo.y, hi.x, hi.y};
-    };
-    auto fragA = [&](const char* buf, int m, int pc) -> u32x4 { return frag_tr(buf + pc * PIECEB + (wo * MT + m) * 64); };
-    auto fragB = [&](const char* buf, int n, int pc) -> u32x4 { return frag_tr(buf + OPERB + pc * PIECEB + (wi * NTL + n) * 64); };
-    auto H8 = [](u32x4 v) { return __builtin_bit_cast(f16x8, v); };
-
-    Raw4 R0, R1, R2;                                                     // raw operands of stage k live in set k % 3
-    if (nit > 0) {
-        load_plain(0, R0);
-        if (nit > 1) load_plain(1, R1);
-        if (nit > 2) load_plain(2, R2);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) split_half(0, R0, k, 0);
-        if (nit > 3) load_plain(3, R0);
-    }
-    __syncthreads();
-    // stage `it`: 48 MFMAs on image `it`; in front of each tile's three MFMAs half a tile of the split of stage it + 1 (set rn) into the other
-    // buffer; then the loads of stage it + 4 into the set that has just been consumed; one workgroup barrier
-    auto stage = [&](int it, Raw4& rn, auto hot) {
-        constexpr bool HOT = decltype(hot)::value;
-        const char* buf = ldsb + (it & 1) * BUFB;
-        const int bnext = (it + 1) & 1;
-        u32x4 af[MT][2], bn[2], b0, b1;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { af[m][0] = fragA(buf, m, 0); af[m][1] = fragA(buf, m, 1); }
-        bn[0] = fragB(buf, 0, 0); bn[1] = fragB(buf, 0, 1);
-        if constexpr (HOT && !(DBG4 & 1)) wait_set(rn, std::integral_constant<int, 2 * kSet>{});
-#pragma unroll
-        for (int n = 0; n < NTL; ++n) {
-            b0 = bn[0]; b1 = bn[1];
-            if (n + 1 < NTL) { bn[0] = fragB(buf, n + 1, 0); bn[1] = fragB(buf, n + 1, 1); }
-            // the twelve MFMAs of this column block with the three products of a tile FOUR instructions apart (a dependent MFMA waits for its
-            // predecessor's result: with one wave per SIMD nobody else fills that gap), half a tile of the split in front of every third one
-#pragma unroll
-            for (int pm = 0; pm < 12; ++pm) {
-                const int pr3 = pm >> 2, m = pm & 3;
-                if (pm % 3 == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (!(DBG4 & 8)) { if (HOT || it + 1 < nit) split_half(it + 1, rn, 4 * n + pm / 3, bnext); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // smallest terms first: lo*hi, hi*lo, hi*hi
-                acc[m][n] = mfma_f16(H8(af[m][pr3 == 0 ? 1 : 0]), H8(pr3 == 1 ? b1 : b0), acc[m][n]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (HOT) { if constexpr (!(DBG4 & 1)) load_asm(it + 4, rn); }
-        else if (it + 4 < nit) load_plain(it + 4, rn);
-        __syncthreads();
-    };
-    // hipcc does not know the asm loads are in flight: enter and leave the hand-counted loop with everything landed
-    auto drain = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0.x0), "+v"(R0.x1), "+v"(R0.x2), "+v"(R0.x3), "+v"(R0.y0), "+v"(R0.y1), "+v"(R0.y2), "+v"(R0.y3),
-                     "+v"(R1.x0), "+v"(R1.x1), "+v"(R1.x2), "+v"(R1.x3), "+v"(R1.y0), "+v"(R1.y1), "+v"(R1.y2), "+v"(R1.y3));
-        asm volatile("" : "+v"(R2.x0), "+v"(R2.x1), "+v"(R2.x2), "+v"(R2.x3), "+v"(R2.y0), "+v"(R2.y1), "+v"(R2.y2), "+v"(R2.y3),
-                     "+v"(R0.sx), "+v"(R0.sy), "+v"(R1.sx), "+v"(R1.sy), "+v"(R2.sx), "+v"(R2.sy));
-    };
-    int it = 0;
-    drain();
-    for (; it + 6 < nit; it += 3) {                                      // hot: stage it + 2 loads stage it + 6 <= nit - 1
-        stage(it, R1, std::true_type{});
-        stage(it + 1, R2, std::true_type{});
-        stage(it + 2, R0, std::true_type{});
-    }
-    drain();
-    for (; it < nit; it += 3) {
-        stage(it, R1, std::false_type{});
-        if (it + 1 < nit) stage(it + 1, R2, std::false_type{});
-        if (it + 2 < nit) stage(it + 2, R0, std::false_type{});
-    }
-
-    float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride;
-    float* dB = dW + (int64_t)a.Hs * a.Hs;
-    if (nit > 0) {
-        const int l32 = lane & 31, hh = lane >> 5;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int o = (wo * MT + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-#pragma unroll
-                for (int n = 0; n < NTL; ++n) {
-                    const int i = (wi * NTL + n) * 32 + l32;
-                    if constexpr ((DBG4 & 64) != 0) asm volatile("" :: "v"(acc[m][n][e]));
-                    else atomicAdd(dW + (int64_t)o * a.Hs + i, acc[m][n][e] * inv_p);
-                }
-            }
-        const float bun = 1.0f / scX[1];                                 // the bias sums ran in zbar's layer scale
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = bsum[t][e];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (li == 0) atomicAdd(dB + 16 * (4 * wave + t) + 4 * q + e, v * bun);
-            }
-    }
-    if (clk_on && tid == 0) {
-        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
-        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-    }
-}
-#ifndef DUDF_WGRAD4_DBG
-#define DUDF_WGRAD4_DBG 0          // timing experiments only (wrong results): 1 no loads in the loop, 8 no split, 64 no output atomics
-#endif
-__global__ __launch_bounds__(256) DUDF_NO_PK void wgrad_hidden4_f16p24_kernel(WgradArgs a) { wgrad4_body<DUDF_WGRAD4_DBG>(a); }
-
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
 //   dW_1[o][d] | db_1[o] = sum_c  q_1[o][c] * gbar[c][d]  +  zbar_1[o][c] * x4[c][d]      (d = 3 is the bias: x4[c][3])
 //   dW_out[f]            = sum_c  A_L[f][c] * x4[c][3]   +  ybar[c] * s_L[f][c]
@@ -1533,7 +1283,7 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
             attr2 = true;
         }
         // option wgrad_family = 2 keeps the per-wave split kernel for the 256-wide tiles (A/B testing)
-        const bool per_wave = dudf_opt_wgrad_family() == 2;       // (3: the four-wave kernel of the 24-bit operands, below)
+        const bool per_wave = dudf_opt_wgrad_family() == 2;
         if constexpr (H == 256) {
             if (a.p24 && per_wave) return DUDF_E_UNSUPPORTED;
             if (!per_wave) {
@@ -1561,18 +1311,6 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t4);
                         if (e != hipSuccess) return (int)e;
                         attr5 = true;
-                    }
-                    if (dudf_opt_wgrad_family() == 3) {                          // one wave per SIMD: 4 waves x 128 x 128 outputs (option, round 6)
-                        static bool attr7 = false;
-                        const size_t smem_4 = 2 * (size_t)(2 * 2 * 16 * 576);
-                        if (!attr7) {
-                            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hidden4_f16p24_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_4);
-                            if (e != hipSuccess) return (int)e;
-                            attr7 = true;
-                        }
-                        hipLaunchKernelGGL(wgrad_hidden4_f16p24_kernel, dim3(nl, nsplit), dim3(256), smem_4, st, a);
-                        return (int)hipGetLastError();
                     }
                     if (dudf_opt_wgrad_buffers() == 4) hipLaunchKernelGGL((wgrad_hidden_f16p24_kernel<H, 25>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t4, st, a);
                     else hipLaunchKernelGGL((wgrad_hidden_f16p24_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t, st, a);
