@@ -53,7 +53,7 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"split_quads", 0, 1, 1},              // the Hessian quads / jets on fp16x3 as well (0: bf16x6)
     {"sweep_family", 0, 1, 1},             // 1 = the 16-bit-core sweeps where built; 0 = the f32-input MFMA kernel everywhere (A/B reference)
     {"stash", 0, 15, DUDF_STASH_DEFAULT},  // REQUESTED stash mask (dudf_stash_mode reports what a workspace gets)
-    {"wgrad_family", 0, 3, 0},             // weight-gradient GEMM: 0 = cooperative split (default), 1 = f32-input MFMA, 2 = bf16x6 per-wave split
+    {"wgrad_family", 0, 2, 0},             // weight-gradient GEMM: 0 = cooperative split (default), 1 = f32-input MFMA, 2 = bf16x6 per-wave split
     {"wgrad_tr", 0, 1, 0},                 // fp32 rows staged through the [column][feature] image + transposed fragment reads
     {"pair_launch", 0, 1, 1},              // quads + plain columns of a training sweep in ONE grid
     {"wgrad_max_workgroups", 8, 256, 256}, // cap of the weight-gradient GEMM's grid (a multi-GPU step leaves CUs to RCCL)
@@ -91,7 +91,7 @@ int dudf_stash_p24_enabled(int H, int L) {
     int want = g_opt[OPT_STASH] & 7;
     if (want != 0 && want != 6 && want != 7) want = 6;
     if (!(use_bf16_sweeps() && dudf_split_fp16() && (dudf_split_mask() & 47) == 47)) want = 0;
-    if (g_opt[OPT_WGRAD_FAMILY] != 0 && g_opt[OPT_WGRAD_FAMILY] != 3) want &= 6;       // f32 / per-wave weight-gradient kernels read fp32 rows
+    if (g_opt[OPT_WGRAD_FAMILY] != 0) want &= 6;       // f32 / per-wave weight-gradient kernels read fp32 rows
     if (H == 256 && L >= 2 && L <= 32) return want;
     // the 512-wide kernel relays S, Q, A, Z through the stash as fp32; R, E, C are not relays.  (Round 5 built the relay as the
     // fixed-point array — every single-step tolerance held, the 12-step trajectory did not: 6e-4 against 7e-7, the rounding enters

@@ -1073,277 +1073,6 @@ __global__ __launch_bounds__(64 * WG<H>::WO * WG<H>::WI) DUDF_NO_PK void wgrad_h
     wgrad_hidden_bf16p_body<H, VAR, 1, 1>(a);
 }
 
-// ---- producer / consumer waves (round 6, option wgrad_family = 3) ---------------------------------------------------------------------------
-// tools/micro/selfissue.hip: on gfx950 a wave's own vector instructions do not hide under its own MFMAs; a SIMD partner's do.  The kernel above
-// lets both partners do both jobs and take turns (hand-over 0.09 ms, fragment reads in front of every burst 0.09 ms).  Here the partners are
-// SPECIALISED: waves 0-3 (one per SIMD) only multiply — 64 x 128 outputs each of a 256 x 128 tile, fragments of the next image read under the
-// MFMAs of this one — and waves 4-7 only produce: loads, 24-bit decode, fp16 split, image writes.  No turn-taking: an image ring of four
-// buffers with two counters per wave (images written / images read), polled by the wave that needs them.  The other half of a layer's 256
-// columns of dW is another workgroup (grid.z) that reads the same X rows — neighbours in the launch order, same XCD, second read from L2.
-typedef unsigned dudf_u3w __attribute__((ext_vector_type(3)));
-struct RawPC { dudf_u3w x0, x1, x2, x3, y0, y1; float sx, sy; };          // a producer's share of one stage: 4 X tiles, 2 Y tiles, two column scales
-template <int DBG4>
-__device__ __forceinline__ void wgrad_pc_body(const WgradArgs& a) {
-    constexpr int NB = 4;
-    constexpr int ROWX = 576, ROWY = 320;                                  // [column k][feature] fp16 rows: 256 (128) features + 64 bytes
-    constexpr int PIECEX = 16 * ROWX, PIECEY = 16 * ROWY, OPERX = 2 * PIECEX, BUFB = OPERX + 2 * PIECEY;     // 28 KiB per image
-    extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave < 4;
-    const int cw = wave & 3;                                               // consumer c / producer p: same SIMD for equal cw
-    const int q = lane >> 4, li = lane & 15;
-    const int j = (int)blockIdx.x + a.j0, by = (int)blockIdx.y, nsplit = (int)gridDim.y, half = (int)blockIdx.z;
-    const int steps16 = a.steps_total * (KT / KB);
-    const int s0 = (int)((int64_t)steps16 * by / nsplit), s1 = (int)((int64_t)steps16 * (by + 1) / nsplit);
-    const bool clk_on = a.clk != nullptr && blockIdx.x == 0 && by == 0 && half == 0;
-    const unsigned long long clk_t0 = clk_on ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int64_t lstride = a.stash_layer / 4 * 3;
-    const int npair = a.have_g ? 2 : 1;
-    const int nit = npair * (s1 - s0);
-    auto pair_of = [&](int it) { return a.have_g ? (it & 1) : 1; };
-    auto step_of = [&](int it) { return s0 + (a.have_g ? (it >> 1) : it); };
-    float scX0, scX1, scY0, scY1, inv_p;                                   // (scalars, not arrays: a run-time index would put them in scratch)
-    {
-        const int eq = dudf_exp_above(a.amax[0 * a.L + j + 1]), eA = dudf_exp_above(a.amax[1 * a.L + j]);
-        const int ez = dudf_exp_above(a.amax[2 * a.L + j + 1]);
-        const int esh = dudf_exp_above(a.amax[3 * a.L + j]);
-        const int es = esh > 1 ? esh : 1;
-        const int P1l = 30 - eq - eA, P2l = 30 - ez - es;
-        const int P = (a.have_g && P1l < P2l) ? P1l : P2l;
-        scX0 = dudf_pow2(15 - eq - (P1l - P)); scY0 = dudf_pow2(15 - eA);
-        scX1 = dudf_pow2(15 - ez - (P2l - P)); scY1 = dudf_pow2(15 - es);
-        inv_p = dudf_pow2(-P);
-    }
-    // progress words (one 256-byte block behind the images): 0-3 images written by producer p, 4-7 images read by consumer c
-    unsigned* flags = reinterpret_cast<unsigned*>(ldsb + NB * BUFB);
-    if (tid < 64) flags[tid] = 0;
-    __syncthreads();
-    const unsigned flag0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(ldsb + NB * BUFB);
-    auto publish = [&](unsigned word, unsigned value) {                     // lane 0 writes `value` into progress word `word`
-        unsigned keep, vt; uint64_t ex;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %2, exec\n\ts_mov_b64 exec, 1\n\t"
-                     "v_mov_b32 %1, %4\n\tds_write_addtid_b32 %1\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&v"(vt), "=&s"(ex) : "s"(flag0 + 4u * word), "s"(value) : "memory");
-    };
-    auto poll = [&](unsigned need, unsigned mask) {                         // until every word selected by `mask` (bit i = word i) is >= need
-        unsigned keep, vt, t0;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n"
-                     ".Ldudf_pcpoll%=:\n\t"
-                     "ds_read_addtid_b32 %1\n\ts_waitcnt lgkmcnt(0)\n\t"
-                     "v_cmp_le_u32 vcc, %4, %1\n\ts_and_b32 %2, vcc_lo, %5\n\t"
-                     "s_cmp_eq_u32 %2, %5\n\t"
-                     "s_cbranch_scc1 .Ldudf_pcdone%=\n\ts_sleep 1\n\ts_branch .Ldudf_pcpoll%=\n"
-                     ".Ldudf_pcdone%=:\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&v"(vt), "=&s"(t0) : "s"(flag0), "s"(need), "s"(mask) : "memory", "vcc", "scc");
-    };
-
-    if (consumer) {
-        // ---- waves 0-3: 64 x 128 outputs each — rows 64 c .. 64 c + 63 of X against the 128 features of this half of Y ---------------------
-        constexpr int MT = 2, NTL = 4;
-        f32x16 acc[MT][NTL];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NTL; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-        const int c_k = 8 * (lane >> 5) + ((lane & 15) >> 2), c_u = 4 * ((lane >> 4) & 1) + (lane & 3);
-        const int sx0 = (c_k >> 1) & 7, sx1 = ((c_k + 4) >> 1) & 7;
-        const int ax0 = c_k * ROWX + 8 * (c_u ^ sx0), ax1 = (c_k + 4) * ROWX + 8 * (c_u ^ sx1);
-        const int ay0 = c_k * ROWY + 8 * (c_u ^ sx0), ay1 = (c_k + 4) * ROWY + 8 * (c_u ^ sx1);
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        auto tr2 = [&](const char* b0, const char* b1) -> u32x4 {
-            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b0));
-            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b1));
-            return u32x4{lo.x, lo.y, hi.x, hi.y};
-        };
-        auto fragA = [&](const char* buf, int m, int pc) -> u32x4 { const char* b = buf + pc * PIECEX + (2 * cw + m) * 64; return tr2(b + ax0, b + ax1); };
-        auto fragB = [&](const char* buf, int n, int pc) -> u32x4 { const char* b = buf + OPERX + pc * PIECEY + n * 64; return tr2(b + ay0, b + ay1); };
-        auto H8 = [](u32x4 v) { return __builtin_bit_cast(f16x8, v); };
-        for (int it = 0; it < nit; ++it) {
-            const char* buf = ldsb + (it & (NB - 1)) * BUFB;
-            poll((unsigned)it + 1u, 0xfu);                                  // image `it` written by all four producers
-            u32x4 af[MT][2], bn[2], b0, b1;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { af[m][0] = fragA(buf, m, 0); af[m][1] = fragA(buf, m, 1); }
-            bn[0] = fragB(buf, 0, 0); bn[1] = fragB(buf, 0, 1);
-#pragma unroll
-            for (int n = 0; n < NTL; ++n) {
-                b0 = bn[0]; b1 = bn[1];
-                if (n + 1 < NTL) { bn[0] = fragB(buf, n + 1, 0); bn[1] = fragB(buf, n + 1, 1); }
-                __builtin_amdgcn_sched_barrier(0x76);                       // LDS reads and MFMAs keep their order: fragments one block ahead
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f32x16 c = acc[m][n];
-                    c = mfma_f16(H8(af[m][1]), H8(b0), c);                   // smallest terms first: lo*hi, hi*lo, hi*hi
-                    c = mfma_f16(H8(af[m][0]), H8(b1), c);
-                    c = mfma_f16(H8(af[m][0]), H8(b0), c);
-                    acc[m][n] = c;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            publish(4u + (unsigned)cw, (unsigned)it + 1u);                  // behind this image's last fragment read (LDS runs a wave's operations in order)
-        }
-        if (nit > 0) {
-            float* dW = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride;
-            const int l32 = lane & 31, hh = lane >> 5;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int o = (cw * MT + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-#pragma unroll
-                    for (int n = 0; n < NTL; ++n) {
-                        const int i = 128 * half + n * 32 + l32;
-                        if constexpr ((DBG4 & 64) != 0) asm volatile("" :: "v"(acc[m][n][e]));
-                        else atomicAdd(dW + (int64_t)o * a.Hs + i, acc[m][n][e] * inv_p);
-                    }
-                }
-        }
-    } else {
-        // ---- waves 4-7: producer p stages X tiles 4 p .. 4 p + 3 and the Y tiles 2 p, 2 p + 1 of this half; lane = (q, li) as in the sweeps --------
-        const char* Xa = reinterpret_cast<const char*>(a.Q + (int64_t)(j + 1) * lstride); const char* Xb = reinterpret_cast<const char*>(a.Z + (int64_t)(j + 1) * lstride);
-        const char* Ya = reinterpret_cast<const char*>(a.A + (int64_t)j * lstride); const char* Yb = reinterpret_cast<const char*>(a.S + (int64_t)j * lstride);
-        const float* FXa = a.fxQ + (int64_t)(j + 1) * a.np; const float* FXb = a.fxZ + (int64_t)(j + 1) * a.np;
-        const float* FYa = a.fxA + (int64_t)j * a.np; const float* FYb = a.fxS + (int64_t)j * a.np;
-        const int64_t ngrp = a.np >> 4;
-        const unsigned vstep = (unsigned)(ngrp * 768);
-        const unsigned vx0 = (unsigned)(lane * 12) + (unsigned)(4 * cw) * vstep;
-        const unsigned vy0 = (unsigned)(lane * 12) + (unsigned)(8 * half + 2 * cw) * vstep;
-        const unsigned li4 = (unsigned)li * 4u;
-        const int sw = (li >> 1) & 7;
-        const int wxe = li * ROWX + 128 * cw + 8 * (q ^ sw), wxo = li * ROWX + 128 * cw + 8 * ((4 + q) ^ sw);
-        const int wye = OPERX + li * ROWY + 64 * cw + 8 * (q ^ sw), wyo = OPERX + li * ROWY + 64 * cw + 8 * ((4 + q) ^ sw);
-        const float bm_quad = ((lane & 3) == 0) ? 1.f : 0.f;
-        f32x4 bsum[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto load_plain = [&](int it, RawPC& r) {
-            const int pr = pair_of(it);
-            const int64_t st = step_of(it);
-            const char* xs = (pr ? Xb : Xa) + st * 768 + vx0;
-            const char* ys = (pr ? Yb : Ya) + st * 768 + vy0;
-            auto ld = [](const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const dudf_u3w*>(p)); };
-            r.x0 = ld(xs); r.x1 = ld(xs + vstep); r.x2 = ld(xs + 2 * (size_t)vstep); r.x3 = ld(xs + 3 * (size_t)vstep);
-            r.y0 = ld(ys); r.y1 = ld(ys + vstep);
-            r.sx = (pr ? FXb : FXa)[st * KB + li];
-            r.sy = (pr ? FYb : FYa)[st * KB + li];
-        };
-        constexpr int kSet = 8;                                             // vector-memory instructions per register set
-        auto load_asm = [&](int it, RawPC& r) {
-            const int pr = pair_of(it);
-            const int64_t st = step_of(it);
-            auto sgpr64 = [](const void* p) {
-                const uint64_t g = (uint64_t)(size_t)p;
-                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)g), hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
-                return ((uint64_t)hi << 32) | lo;
-            };
-            const uint64_t xb = sgpr64((pr ? Xb : Xa) + st * 768), yb = sgpr64((pr ? Yb : Ya) + st * 768);
-            const uint64_t fxb = sgpr64((pr ? FXb : FXa) + st * KB), fyb = sgpr64((pr ? FYb : FYa) + st * KB);
-            asm volatile("global_load_dwordx3 %0, %4, %8 nt\n\tglobal_load_dwordx3 %1, %5, %8 nt\n\t"
-                         "global_load_dwordx3 %2, %6, %8 nt\n\tglobal_load_dwordx3 %3, %7, %8 nt"
-                         : "=&v"(r.x0), "=&v"(r.x1), "=&v"(r.x2), "=&v"(r.x3)
-                         : "v"(vx0), "v"(vx0 + vstep), "v"(vx0 + 2 * vstep), "v"(vx0 + 3 * vstep), "s"(xb) : "memory");
-            asm volatile("global_load_dwordx3 %0, %2, %4 nt\n\tglobal_load_dwordx3 %1, %3, %4 nt"
-                         : "=&v"(r.y0), "=&v"(r.y1) : "v"(vy0), "v"(vy0 + vstep), "s"(yb) : "memory");
-            asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4" : "=&v"(r.sx), "=&v"(r.sy) : "v"(li4), "s"(fxb), "s"(fyb) : "memory");
-        };
-        auto wait_set = [&](RawPC& r, auto younger) {
-            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r.x0), "+v"(r.x1), "+v"(r.x2), "+v"(r.x3), "+v"(r.y0), "+v"(r.y1), "+v"(r.sx), "+v"(r.sy)
-                         : "n"(decltype(younger)::value));
-        };
-        auto split_tile = [&](const dudf_u3w g, const float scl, char* dst, int piece_bytes, f32x4* bs, const float bmask) {
-            const unsigned m = 0x00ffffffu, two = 0x40000000u;
-            const unsigned t0 = (g.x & m) | two, t1 = (g.y & m) | two, t2 = (g.z & m) | two;
-            const unsigned y = __builtin_amdgcn_perm(g.y, g.x, 0x0c0c0703u);
-            const unsigned t3 = __builtin_amdgcn_perm(g.z, y, 0x0c070100u) | two;
-            const float m3 = -3.0f * scl;
-            const f32x4 v = {__builtin_fmaf(__uint_as_float(t0), scl, m3), __builtin_fmaf(__uint_as_float(t1), scl, m3),
-                             __builtin_fmaf(__uint_as_float(t2), scl, m3), __builtin_fmaf(__uint_as_float(t3), scl, m3)};
-            if (bs) *bs += bmask * v;
-            const f16x2 h0 = __builtin_convertvector(f32x2{v[0], v[1]}, f16x2), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, f16x2);
-            f32x2 r0, r1;
-            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0.x) : "v"(v[0]), "v"(h0));
-            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r0.y) : "v"(v[1]), "v"(h0));
-            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r1.x) : "v"(v[2]), "v"(h1));
-            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1.y) : "v"(v[3]), "v"(h1));
-            const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-            *reinterpret_cast<u32x2*>(dst + piece_bytes) = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
-        };
-        auto split = [&](int it, const RawPC& r) {
-            const int pr = pair_of(it);
-            char* base = ldsb + (it & (NB - 1)) * BUFB;
-            const float hs = ((int64_t)step_of(it) * KB < a.ncol_h) ? 1.f : 0.f;
-            const float bmask = (pr == 1 ? 1.f : 0.f) * (1.f + hs * (bm_quad - 1.f));
-            const float sx = r.sx * (pr ? scX1 : scX0), sy = r.sy * (pr ? scY1 : scY0);
-            split_tile(r.x0, sx, base + wxe, PIECEX, &bsum[0], bmask);
-            split_tile(r.x1, sx, base + wxo, PIECEX, &bsum[1], bmask);
-            split_tile(r.x2, sx, base + wxe + 64, PIECEX, &bsum[2], bmask);
-            split_tile(r.x3, sx, base + wxo + 64, PIECEX, &bsum[3], bmask);
-            split_tile(r.y0, sy, base + wye, PIECEY, nullptr, 0.f);
-            split_tile(r.y1, sy, base + wyo, PIECEY, nullptr, 0.f);
-        };
-        RawPC R0, R1, R2;                                                   // raw operands of image k live in set k % 3
-        if (nit > 0) load_plain(0, R0);
-        if (nit > 1) load_plain(1, R1);
-        if (nit > 2) load_plain(2, R2);
-        auto drain = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0.x0), "+v"(R0.x1), "+v"(R0.x2), "+v"(R0.x3), "+v"(R0.y0), "+v"(R0.y1), "+v"(R0.sx), "+v"(R0.sy),
-                         "+v"(R1.x0), "+v"(R1.x1), "+v"(R1.x2), "+v"(R1.x3), "+v"(R1.y0), "+v"(R1.y1), "+v"(R1.sx), "+v"(R1.sy));
-            asm volatile("" : "+v"(R2.x0), "+v"(R2.x1), "+v"(R2.x2), "+v"(R2.x3), "+v"(R2.y0), "+v"(R2.y1), "+v"(R2.sx), "+v"(R2.sy));
-        };
-        // image k: its operands have landed (two younger sets stay in flight), its buffer is free (every consumer has read image k - NB),
-        // split, publish, refill the set with image k + 3
-        auto produce = [&](int k, RawPC& r, auto hot) {
-            constexpr bool HOT = decltype(hot)::value;
-            if constexpr (HOT && !(DBG4 & 1)) wait_set(r, std::integral_constant<int, 2 * kSet>{});
-            if (k >= NB) poll((unsigned)(k - NB) + 1u, 0xf0u);
-            if constexpr (!(DBG4 & 8)) split(k, r);
-            publish((unsigned)cw, (unsigned)k + 1u);
-            if constexpr (HOT) { if constexpr (!(DBG4 & 1)) load_asm(k + 3, r); }
-            else if (k + 3 < nit) load_plain(k + 3, r);
-        };
-        int k = 0;
-        drain();
-        for (; k + 5 < nit; k += 3) {                                       // hot: image k + 2 loads image k + 5 <= nit - 1
-            produce(k, R0, std::true_type{});
-            produce(k + 1, R1, std::true_type{});
-            produce(k + 2, R2, std::true_type{});
-        }
-        drain();
-        for (; k < nit; k += 3) {
-            produce(k, R0, std::false_type{});
-            if (k + 1 < nit) produce(k + 1, R1, std::false_type{});
-            if (k + 2 < nit) produce(k + 2, R2, std::false_type{});
-        }
-        if (nit > 0 && half == 0) {                                         // bias gradient (both halves see the same X: one of them adds it)
-            float* dB = a.dtheta + a.off_hid + (int64_t)j * a.hid_stride + (int64_t)a.Hs * a.Hs;
-            const float bun = 1.0f / scX1;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = bsum[t][e];
-                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                    if (li == 0) atomicAdd(dB + 16 * (4 * cw + t) + 4 * q + e, v * bun);
-                }
-        }
-    }
-    if (clk_on && tid == 0) {
-        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
-        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-    }
-}
-#ifndef DUDF_WGRADPC_DBG
-#define DUDF_WGRADPC_DBG 0         // timing experiments only (wrong results): 1 no loads in the loop, 8 no split, 64 no output atomics
-#endif
-__global__ __launch_bounds__(512) DUDF_NO_PK void wgrad_pc_f16p24_kernel(WgradArgs a) { wgrad_pc_body<DUDF_WGRADPC_DBG>(a); }
-
 // ---- first and last layer: thin reductions over columns (bandwidth-bound, VALU) -------------------------
 //   dW_1[o][d] | db_1[o] = sum_c  q_1[o][c] * gbar[c][d]  +  zbar_1[o][c] * x4[c][d]      (d = 3 is the bias: x4[c][3])
 //   dW_out[f]            = sum_c  A_L[f][c] * x4[c][3]   +  ybar[c] * s_L[f][c]
@@ -1582,21 +1311,6 @@ int launch_hidden(const WgradArgs& a, hipStream_t st) {
                                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t4);
                         if (e != hipSuccess) return (int)e;
                         attr5 = true;
-                    }
-                    if (dudf_opt_wgrad_family() == 3) {                          // producer / consumer waves, 256 x 128 tiles (option, round 6)
-                        static bool attr7 = false;
-                        const size_t smem_pc = 4 * (size_t)(2 * 16 * 576 + 2 * 16 * 320) + 256;
-                        if (!attr7) {
-                            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pc_f16p24_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pc);
-                            if (e != hipSuccess) return (int)e;
-                            attr7 = true;
-                        }
-                        int ns2 = maxwg / (2 * nl);                                // two workgroups (halves of the columns of dW) per (layer, column split)
-                        if (ns2 > a.steps_total) ns2 = a.steps_total;
-                        if (ns2 < 1 || dudf_deterministic()) ns2 = 1;
-                        hipLaunchKernelGGL(wgrad_pc_f16p24_kernel, dim3(nl, ns2, 2), dim3(512), smem_pc, st, a);
-                        return (int)hipGetLastError();
                     }
                     if (dudf_opt_wgrad_buffers() == 4) hipLaunchKernelGGL((wgrad_hidden_f16p24_kernel<H, 25>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t4, st, a);
                     else hipLaunchKernelGGL((wgrad_hidden_f16p24_kernel<H, 9>), dim3(nl, nsplit, ntz), dim3(NTHR), smem_t, st, a);
